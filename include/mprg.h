@@ -1,0 +1,126 @@
+/*
+ * mprg.h — C ABI of libmprg_hip.so: the MI355X (gfx950) kernels of the `from_msa` PRG-construction hot path.
+ *
+ * The reference (iqbal-lab-org/make_prg v0.5.0) is pure Python and has no FFI; each entry point below replaces the
+ * body of one (or a fused group of) reference function(s), cited as file:line relative to /root/reference/make_prg/.
+ * INTEGRATION.md shows the ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  All pointers are DEVICE pointers owned by the caller (the Python host
+ *     allocates them as PyTorch-ROCm tensors) unless the name ends in _host.
+ *   - Every function takes the hipStream_t to enqueue on (as void*), enqueues asynchronously and never
+ *     synchronises.  Return value: 0 = ok, negative = error (mprg_last_error() gives text).
+ *   - A call processes a BATCH of node views (one recursion level of many MSAs): one launch per level.
+ *
+ * Data layout
+ *   - Cells are 1-byte codes: 0 A, 1 C, 2 G, 3 T, 4 '-', 5 R, 6 Y, 7 K, 8 M, 9 S, 10 W, 11 N.
+ *   - `arena` holds every MSA twice: row-major (row r, column c at rm_base + r*pitchC + c; pitchC % 16 == 0) and
+ *     transposed (cm_base + c*pitchS + r; pitchS % 16 == 0).  Column-parallel kernels read the first, row-parallel
+ *     kernels the second, so both kinds of access are coalesced.
+ *   - A view is MPRG_VIEW_FIELDS int64 values (see enum): a row subset (identity or an index list in `rowidx`) and a
+ *     closed-open column range of one MSA.  col_off / row_off are exclusive prefix sums over the batch and index
+ *     the per-column / per-row outputs.
+ */
+#ifndef MPRG_H
+#define MPRG_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  MPRG_V_RM_BASE = 0, MPRG_V_CM_BASE = 1, MPRG_V_PITCH_C = 2, MPRG_V_PITCH_S = 3, MPRG_V_ROWS_OFF = 4,
+  MPRG_V_N_ROWS = 5, MPRG_V_COL0 = 6, MPRG_V_N_COLS = 7, MPRG_V_COL_OFF = 8, MPRG_V_ROW_OFF = 9,
+  MPRG_V_AUX0 = 10, MPRG_V_AUX1 = 11, MPRG_VIEW_FIELDS = 12
+};
+enum { MPRG_CODE_GAP = 4, MPRG_CODE_N = 11, MPRG_N_CODES = 12 };
+enum { MPRG_IV_MATCH = 0, MPRG_IV_NONMATCH = 1 };
+/* per-view status bits written by mprg_partition */
+enum { MPRG_ST_PARTITION_ERROR = 1, MPRG_ST_ALL_N_SLICE = 2 };
+/* per-fit status bits written by the KMeans kernels */
+enum { MPRG_KM_EMPTY_CLUSTER = 1 };
+
+const char *mprg_version(void);
+const char *mprg_last_error(void);
+/* number of compute units of the current device (grid sizing); <0 on error */
+int mprg_device_cus(void);
+
+/* A2 + A8 — utils/seq_utils.py:219-239 (get_consensus_from_MSA) and :193-216 (all-gap columns).
+ * work: n_items x 3 int32 {view, first column of a 1024-column tile (relative to the view, multiple of 4 in
+ * absolute arena columns), first row position of a row chunk}; rows_per_chunk rows per item.
+ * out_mask[col_off + c] (uint32, must be zeroed) receives the OR over the view's rows of (1 << code). */
+int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int32_t *work,
+                      int n_items, int rows_per_chunk, uint32_t *out_mask, void *stream);
+
+/* A3-A6 — from_msa/interval_partition.py:81-252 (IntervalPartitioner) with utils/seq_utils.py:37-42
+ * (has_empty_sequence) and the <2-sequences test of :187-217.  One workgroup per view.
+ * in:  mask (from mprg_column_masks), min_match_length.
+ * scratch: maxrun uint32[total_cols] (zeroed), stack int32[4*total_cols], ivflag int32[total_cols*2] (zeroed)
+ * out: iv int32[3*total_cols] as {start, stop, type} triples at 3*col_off, n_iv int32[n_views],
+ *      status int32[n_views]. */
+int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
+                   const uint32_t *mask, int min_match_length, uint32_t *maxrun, int32_t *stack, int32_t *ivflag,
+                   int32_t *iv, int32_t *n_iv, int32_t *status, void *stream);
+
+/* A9a/A13/A16 — from_msa/cluster_sequences.py:220-233 (ungap, group identical rows in first-appearance order),
+ * utils/seq_utils.py:58-70 (unique gapped / ungapped counts).  One workgroup per view.
+ * views[AUX0] = byte offset of this view's region in `ucodes` (n_cols * n_rows_pad bytes, n_rows_pad =
+ * round_up(n_rows,16)); ungapped codes are stored transposed: character j of row position i at j*n_rows_pad + i.
+ * out (per row, at row_off): ulen int32, rep_u int32 (smallest row position with identical ungapped content),
+ * rep_g int32 (same for gapped content).  scratch: hashes uint64[2*total_rows]. */
+int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
+                      uint8_t *ucodes, uint64_t *hashes, int32_t *ulen, int32_t *rep_u, int32_t *rep_g,
+                      void *stream);
+
+/* A9b — from_msa/cluster_sequences.py:26-38 (count_distinct_kmers): k-mer dictionary in first-appearance order.
+ * One workgroup per clustering problem.  prob: n_probs x MPRG_PROB_FIELDS int64 (see enum).  seqrow int32[]:
+ * row positions (within the view) of the D distinct long sequences in first-appearance order.
+ * table: uint64 keys[cap] then uint32 minocc[cap], uint32 id[cap] per problem (cap = power of two >= 2*T).
+ * out_V[n_probs] = number of distinct k-mers. */
+enum {
+  MPRG_P_VIEW = 0, MPRG_P_D = 1, MPRG_P_SEQROW_OFF = 2, MPRG_P_T = 3, MPRG_P_TABLE_OFF = 4, MPRG_P_TABLE_CAP = 5,
+  MPRG_P_OCC_OFF = 6, MPRG_P_V = 7, MPRG_P_X_OFF = 8, MPRG_P_WS_OFF = 9, MPRG_P_LABEL_OFF = 10, MPRG_P_FLAG_OFF = 11,
+  MPRG_PROB_FIELDS = 12
+};
+int mprg_kmer_dictionary(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size,
+                         const uint8_t *ucodes, const int32_t *ulen, const int32_t *seqrow, int64_t *occ_off,
+                         uint8_t *table, uint8_t *first_flag, int32_t *out_V, void *stream);
+/* A9c — cluster_sequences.py:41-56 (count_kmer_occurrences): dense D x V count matrix (float64, zeroed by caller)
+ * at prob[X_OFF] (in doubles) inside `xcounts`. */
+int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size, const uint8_t *ucodes,
+                     const int32_t *ulen, const int32_t *seqrow, const int64_t *occ_off, const uint8_t *table,
+                     double *xcounts, void *stream);
+
+/* A11 — the reference's KMeans(n_clusters=k, random_state=2, algorithm="elkan").fit(X).predict(X)
+ * (cluster_sequences.py:262-266; arithmetic restated from scikit-learn, see oracle/kmeans_oracle.c) with
+ * n_init restarts.  Three launches:
+ *   mprg_kmeans_prepare : per problem, centre X (prob[WS_OFF] workspace), row norms, tolerance.   (once per problem)
+ *   mprg_kmeans_restarts: per (problem, restart): k-means++ from `uniforms` + Elkan iterations.
+ *   mprg_kmeans_select  : per problem: best restart by the reference's rule, then predict().
+ * uniforms_host: n_init * (1 + (k-1)*(2+int(ln k))) doubles of numpy RandomState(2).random_sample (host pointer,
+ * copied by the call).  labels int32 at prob[LABEL_OFF]; km_status int32[n_probs]; km_info double[4*n_probs]
+ * = {inertia, n_iter, best restart, n distinct labels}.
+ * Workspace size per problem (doubles): mprg_kmeans_workspace_doubles(D, V, k_max, n_init). */
+int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_init);
+int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, void *stream);
+int mprg_kmeans_restarts(const int64_t *prob, int n_probs, int k, int n_init, const double *uniforms_dev,
+                         double *ws, int32_t *km_status, void *stream);
+int mprg_kmeans_select(const int64_t *prob, int n_probs, int k, int n_init, const double *xcounts, double *ws,
+                       int32_t *labels, int32_t *km_status, double *km_info, void *stream);
+/* fills out[n] with numpy.random.RandomState(seed).random_sample(n) (host memory; MT19937) */
+void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
+
+/* A10 — cluster_sequences.py:59-111 (majority string, Hamming distance, one-reference-like test, cluster_further).
+ * One workgroup per problem.  member_label int32 per row position of the view at row_off (-1 = row takes no part),
+ * member_key int32 per row (order in which the reference enumerates the cluster's rows; ties in the per-column
+ * majority go to the symbol seen first in that order).  out_further[n_probs] = 1 if some cluster is not
+ * one-reference-like. */
+int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
+                         int n_probs, int k, const int32_t *member_label, const int32_t *member_key,
+                         int32_t *scratch, int32_t *out_further, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,106 @@
+"""Device backend: loads the HIP shared object through ctypes and owns device memory through PyTorch-ROCm.
+
+The product path has exactly one backend, `HipBackend`: libmprg_hip.so (gfx950 code object) + torch.cuda buffers.
+If the library or a GPU is missing this module raises — there is no CPU fallback.  (tests/emu provides a
+test-only stand-in with the same interface that runs the kernel source's logic on the CPU; it is injected
+explicitly by tests and never imported from here.)
+"""
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_PKG, "_lib", "libmprg_hip.so")
+
+c_void_p, c_int, c_int64, c_uint32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint32
+
+# name -> (restype, argtypes); mirrors include/mprg.h
+SIGNATURES = {
+    "mprg_version": (ctypes.c_char_p, []),
+    "mprg_last_error": (ctypes.c_char_p, []),
+    "mprg_device_cus": (c_int, []),
+    "mprg_column_masks": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p, c_void_p]),
+    "mprg_partition": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int] + [c_void_p] * 7),
+    "mprg_ungap_dedupe": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 6),
+    "mprg_kmer_dictionary": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8),
+    "mprg_kmer_counts": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7),
+    "mprg_kmeans_workspace_doubles": (c_int64, [c_int64, c_int64, c_int, c_int]),
+    "mprg_kmeans_prepare": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "mprg_kmeans_restarts": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mprg_kmeans_select": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
+    "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 5),
+    "mprg_random_sample_host": (None, [c_uint32, c_int, c_void_p]),
+}
+
+
+class MprgError(RuntimeError):
+    pass
+
+
+def bind(lib):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+class _Base:
+    """Shared call helper: every kernel entry point returns 0 or raises with the library's message."""
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(*args)
+        if rc != 0:
+            raise MprgError(f"{name} failed ({rc}): {self.lib.mprg_last_error().decode()}")
+
+    def random_sample(self, seed: int, n: int) -> np.ndarray:
+        out = np.empty(n, np.float64)
+        self.lib.mprg_random_sample_host(seed, n, out.ctypes.data)
+        return out
+
+
+class HipBackend(_Base):
+    name = "hip"
+
+    def __init__(self, device: Optional[int] = None, lib_path: str = HIP_LIB_PATH):
+        import torch
+        if not os.path.exists(lib_path):
+            raise MprgError(f"{lib_path} not found: build it with `python __graft_entry__.py build` (hipcc, gfx950)")
+        if not torch.cuda.is_available():
+            raise MprgError("no ROCm device visible: make_prg_amd has no CPU fallback")
+        self.torch = torch
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.lib = bind(ctypes.CDLL(lib_path))
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.n_cus = self.lib.mprg_device_cus()
+
+    # buffers are flat uint8 tensors; sizes in bytes
+    def empty(self, nbytes: int):
+        return self.torch.empty(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
+
+    def zeros(self, nbytes: int):
+        return self.torch.zeros(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes == 0:
+            return self.empty(16)
+        t = self.torch.from_numpy(arr.view(np.uint8).reshape(-1))
+        return t.to(self.device, non_blocking=False)
+
+    def download(self, buf, dtype, count: int) -> np.ndarray:
+        nbytes = int(count) * np.dtype(dtype).itemsize
+        if nbytes == 0:
+            return np.empty(0, dtype)
+        return buf[:nbytes].cpu().numpy().view(dtype)
+
+    def ptr(self, buf) -> int:
+        return buf.data_ptr()
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)

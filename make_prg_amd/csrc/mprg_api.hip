@@ -1,0 +1,159 @@
+// mprg_api.hip — C ABI (include/mprg.h) over the gfx950 kernels of the from_msa hot path.
+// Build (product):  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared mprg_api.hip -o libmprg_hip.so
+// Build (test-only logic emulation, see mprg_platform.h):  g++ -x c++ -DMPRG_CPU_EMU -O2 -ffp-contract=off -mfma ...
+#include "mprg_platform.h"
+#include "../../include/mprg.h"
+#include <stdio.h>
+#include <string.h>
+
+#include "k_columns.inc"
+#include "k_partition.inc"
+#include "k_rows.inc"
+#include "k_kmer.inc"
+#include "k_kmeans.inc"
+#include "k_cluster.inc"
+
+static thread_local char g_err[512] = "";
+static int fail(const char *what) { snprintf(g_err, sizeof g_err, "%s", what); return -1; }
+
+#ifdef MPRG_CPU_EMU
+static int check_launch(const char *) { return 0; }
+#else
+static int check_launch(const char *name) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s: %s", name, hipGetErrorString(e)); return -2; }
+  return 0;
+}
+#endif
+
+#define BLOCK_VIEW 256
+
+extern "C" {
+
+const char *mprg_version(void) {
+#ifdef MPRG_CPU_EMU
+  return "mprg 0.1 (cpu logic emulation — tests only)";
+#else
+  return "mprg 0.1 (hip gfx950)";
+#endif
+}
+const char *mprg_last_error(void) { return g_err; }
+
+int mprg_device_cus(void) {
+#ifdef MPRG_CPU_EMU
+  return 1;
+#else
+  int dev = 0; hipDeviceProp_t p;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail("no HIP device");
+  return p.multiProcessorCount;
+#endif
+}
+
+int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int32_t *work,
+                      int n_items, int rows_per_chunk, uint32_t *out_mask, void *stream) {
+  if (n_items <= 0) return 0;
+  if (rows_per_chunk <= 0) return fail("rows_per_chunk must be positive");
+  LAUNCH(k_column_masks, n_items, CM_THREADS, stream, arena, views, rowidx, work, rows_per_chunk, out_mask);
+  return check_launch("k_column_masks");
+}
+
+int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
+                   const uint32_t *mask, int min_match_length, uint32_t *maxrun, int32_t *stack, int32_t *ivflag,
+                   int32_t *iv, int32_t *n_iv, int32_t *status, void *stream) {
+  if (n_views <= 0) return 0;
+  LAUNCH(k_partition, n_views, BLOCK_VIEW, stream, arena, views, rowidx, mask, min_match_length, maxrun, stack, ivflag,
+         iv, n_iv, status);
+  return check_launch("k_partition");
+}
+
+int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
+                      uint8_t *ucodes, uint64_t *hashes, int32_t *ulen, int32_t *rep_u, int32_t *rep_g,
+                      void *stream) {
+  if (n_views <= 0) return 0;
+  LAUNCH(k_ungap_dedupe, n_views, BLOCK_VIEW, stream, arena, views, rowidx, ucodes, hashes, ulen, rep_u, rep_g);
+  return check_launch("k_ungap_dedupe");
+}
+
+int mprg_kmer_dictionary(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size,
+                         const uint8_t *ucodes, const int32_t *ulen, const int32_t *seqrow, int64_t *occ_off,
+                         uint8_t *table, uint8_t *first_flag, int32_t *out_V, void *stream) {
+  (void)ulen;
+  if (n_probs <= 0) return 0;
+  if (kmer_size < 1 || kmer_size > 16) return fail("k-mer size must be in 1..16 (4-bit packed keys)");
+  LAUNCH(k_kmer_dictionary, n_probs, 512, stream, views, prob, kmer_size, ucodes, seqrow, (const int64_t *)occ_off, table,
+         first_flag, out_V);
+  return check_launch("k_kmer_dictionary");
+}
+
+int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size, const uint8_t *ucodes,
+                     const int32_t *ulen, const int32_t *seqrow, const int64_t *occ_off, const uint8_t *table,
+                     double *xcounts, void *stream) {
+  (void)ulen;
+  if (n_probs <= 0) return 0;
+  if (kmer_size < 1 || kmer_size > 16) return fail("k-mer size must be in 1..16 (4-bit packed keys)");
+  LAUNCH(k_kmer_counts, n_probs, 512, stream, views, prob, kmer_size, ucodes, seqrow, occ_off, table, xcounts);
+  return check_launch("k_kmer_counts");
+}
+
+int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_init) {
+  if (k_max > KM_KMAX) return -1;
+  return km_common_doubles_host(D, V) + (int64_t)n_init * km_restart_doubles_host(D, V);
+}
+
+int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, void *stream) {
+  if (n_probs <= 0) return 0;
+  LAUNCH(k_kmeans_prepare, n_probs, 256, stream, prob, xcounts, ws);
+  return check_launch("k_kmeans_prepare");
+}
+
+int mprg_kmeans_restarts(const int64_t *prob, int n_probs, int k, int n_init, const double *uniforms_dev,
+                         double *ws, int32_t *km_status, void *stream) {
+  if (n_probs <= 0) return 0;
+  if (k < 2 || k > KM_KMAX) return fail("k must be in 2..10");
+  const int n_trials = 2 + (int)log((double)k);
+  LAUNCH(k_kmeans_restart, n_probs * n_init, 256, stream, prob, k, n_init, n_trials, uniforms_dev, ws, km_status);
+  return check_launch("k_kmeans_restart");
+}
+
+int mprg_kmeans_select(const int64_t *prob, int n_probs, int k, int n_init, const double *xcounts, double *ws,
+                       int32_t *labels, int32_t *km_status, double *km_info, void *stream) {
+  (void)km_status;
+  if (n_probs <= 0) return 0;
+  LAUNCH(k_kmeans_select, n_probs, 256, stream, prob, k, n_init, xcounts, ws, labels, km_info);
+  return check_launch("k_kmeans_select");
+}
+
+int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
+                         int n_probs, int k, const int32_t *member_label, const int32_t *member_key,
+                         int32_t *scratch, int32_t *out_further, void *stream) {
+  if (n_probs <= 0) return 0;
+  LAUNCH(k_cluster_further, n_probs, BLOCK_VIEW, stream, arena, views, rowidx, prob, k, member_label, member_key, scratch,
+         out_further);
+  return check_launch("k_cluster_further");
+}
+
+// numpy.random.RandomState(seed).random_sample(n): MT19937, init_genrand seeding, 53-bit doubles
+void mprg_random_sample_host(uint32_t seed, int n, double *out) {
+  uint32_t mt[624];
+  mt[0] = seed;
+  for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+  int idx = 624;
+  auto next = [&]() -> uint32_t {
+    if (idx >= 624) {
+      for (int i = 0; i < 624; i++) {
+        const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+        mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+  };
+  for (int i = 0; i < n; i++) {
+    const uint32_t a = next() >> 5, b = next() >> 6;
+    out[i] = (a * 67108864.0 + b) / 9007199254740992.0;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,611 @@
+"""Level-synchronous from_msa engine: the Python host drives the recursion, the HIP kernels do the array work.
+
+One `BatchEngine.build(msas)` call builds the recursion trees of MANY alignments together.  All node views of one
+recursion level (across every MSA of the batch) go through each kernel in ONE launch, so the number of launches and
+host<->device round trips depends on the tree depth, not on the number of alignments.
+
+Reference being replaced: NodeFactory.build and everything below it (make_prg/recursion_tree.py:401-471 with
+from_msa/interval_partition.py, from_msa/cluster_sequences.py, utils/seq_utils.py); SURVEY.md §8(a) rows A1-A15.
+Host keeps: branch selection (A1), cluster bookkeeping on ids (A12, A14), node numbering (A15), PRG emission (A16).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .backend import MprgError
+from .msa import CODE_GAP, MSA, decode, encode
+
+VF, PF = 12, 12
+BIT_GAP, BIT_N, BITS_IUPAC = 1 << 4, 1 << 11, 0x7E0
+MAX_CLUSTERS = 10   # from_msa/cluster_sequences.py:23
+N_INIT = 10         # scikit-learn 1.3.0 default the reference's pinned environment runs with
+ROWS_PER_CHUNK = 512
+TILE_COLS = 1024
+IUPAC = {"R": "GA", "Y": "TC", "K": "GT", "M": "AC", "S": "GC", "W": "AT", "A": "A", "C": "C", "G": "G", "T": "T"}
+
+
+class SequenceCurationError(Exception):
+    """utils/seq_utils.py:73-74."""
+
+
+class PartitioningError(Exception):
+    """from_msa/interval_partition.py:12-13."""
+
+
+def _align(x: int, a: int) -> int:
+    return (x + a - 1) // a * a
+
+
+@dataclass
+class NodeRec:
+    """One recursion-tree node (host record).  rows: indices into the MSA (None = all rows, in order)."""
+    msa: int
+    parent: int                 # index into EngineResult.nodes, -1 for root
+    level: int                  # nesting level the node is created with
+    rows: Optional[np.ndarray]
+    col0: int
+    ncols: int
+    kind: str = "?"             # "leaf" | "interval" | "cluster"
+    children: List[int] = field(default_factory=list)
+    keep_cols: Optional[np.ndarray] = None    # columns that are not all-gap (device mask), stored-alignment columns
+    consensus: Optional[np.ndarray] = None    # per-column consensus code (0..3) or 255
+    leaf_rows: Optional[np.ndarray] = None    # leaf: view row positions of the distinct ungapped rows, in order
+    node_id: int = -1
+
+
+@dataclass
+class LocusResult:
+    index: int
+    nodes: List[NodeRec]
+    root: int
+    error: Optional[Exception] = None
+    stats: dict = field(default_factory=dict)
+
+
+class BatchEngine:
+    def __init__(self, backend, max_nesting: int = 5, min_match_length: int = 7):
+        self.be = backend
+        self.max_nesting = max_nesting
+        self.L = min_match_length
+        self._uniform_cache: Dict[int, object] = {}
+        self.timers: Dict[str, float] = {}
+        self.counters: Dict[str, float] = dict(cells_all=0, cells_clustered=0, kmeans_bytes=0, fits=0, levels=0,
+                                               launches=0)
+
+    # ------------------------------------------------------------------------------------------------ packing
+    def _pack(self, msas: List[MSA]):
+        """Encode every MSA and lay the batch out in one arena (row-major + transposed copy per MSA)."""
+        self.codes: List[np.ndarray] = []
+        self.bad: Dict[int, Exception] = {}
+        metas = []
+        off = 0
+        for i, m in enumerate(msas):
+            codes = encode(m.data)
+            if (codes == 255).any():
+                # any byte outside ACGT-RYKMSWN ends in SequenceCurationError in the reference (it reaches a
+                # SequenceExpander check in interval partitioning or leaf emission; utils/seq_utils.py:96-104)
+                r, c = np.argwhere(codes == 255)[0]
+                self.bad[i] = SequenceCurationError(
+                    f"A slice of a sequence has a disallowed base ({chr(m.data[r, c])!r} in {m.ids[r]}). Redo sequence curation.")
+                codes = np.where(codes == 255, 0, codes).astype(np.uint8)
+            self.codes.append(codes)
+            S, C = codes.shape
+            pitchC, pitchS = _align(max(C, 1), 16), _align(max(S, 1), 16)
+            rm = off
+            off = _align(rm + S * pitchC, 256)
+            cm = off
+            off = _align(cm + C * pitchS, 256)
+            metas.append((rm, cm, pitchC, pitchS, S, C))
+        arena = np.full(off + 256, 15, np.uint8)
+        for (rm, cm, pitchC, pitchS, S, C), codes in zip(metas, self.codes):
+            if S == 0 or C == 0:
+                continue
+            arena[rm:rm + S * pitchC].reshape(S, pitchC)[:, :C] = codes
+            arena[cm:cm + C * pitchS].reshape(C, pitchS)[:, :S] = codes.T
+        self.meta = metas
+        self.d_arena = self.be.upload(arena)
+        self.counters["arena_bytes"] = int(arena.nbytes)
+
+    # ------------------------------------------------------------------------------------------------ views
+    def _view_table(self, nodes: List[NodeRec], idxs: List[int]):
+        """int64 [n][VF] view descriptors + the row-index pool for these nodes."""
+        n = len(idxs)
+        tab = np.zeros((n, VF), np.int64)
+        pool, pool_off, cache = [], 0, {}
+        col_off = row_off = 0
+        for j, ni in enumerate(idxs):
+            nd = nodes[ni]
+            rm, cm, pitchC, pitchS, S, C = self.meta[nd.msa]
+            if nd.rows is None:
+                roff, nrows = -1, S
+            else:
+                key = id(nd.rows)
+                if key not in cache:
+                    cache[key] = pool_off
+                    pool.append(nd.rows)
+                    pool_off += len(nd.rows)
+                roff, nrows = cache[key], len(nd.rows)
+            tab[j] = (rm, cm, pitchC, pitchS, roff, nrows, nd.col0, nd.ncols, col_off, row_off, 0, 0)
+            col_off += nd.ncols
+            row_off += nrows
+        rowidx = np.concatenate(pool).astype(np.int32) if pool else np.zeros(1, np.int32)
+        return tab, rowidx, col_off, row_off
+
+    @staticmethod
+    def _mask_work(tab: np.ndarray) -> np.ndarray:
+        """Work items {view, tile column, first row} of mprg_column_masks, vectorised over the views."""
+        n = tab.shape[0]
+        lead = tab[:, 6] % 4                                  # col0 % 4: tiles start 4-aligned in arena columns
+        ntile = (tab[:, 7] + lead + TILE_COLS - 1) // TILE_COLS
+        nchunk = (tab[:, 5] + ROWS_PER_CHUNK - 1) // ROWS_PER_CHUNK
+        per = ntile * nchunk
+        total = int(per.sum())
+        view = np.repeat(np.arange(n), per)
+        start = np.repeat(np.cumsum(per) - per, per)
+        k = np.arange(total) - start
+        nch = np.repeat(nchunk, per)
+        tile = k // nch
+        chunk = k % nch
+        work = np.empty((total, 3), np.int32)
+        work[:, 0] = view
+        work[:, 1] = tile * TILE_COLS - np.repeat(lead, per)
+        work[:, 2] = chunk * ROWS_PER_CHUNK
+        return work
+
+    # ------------------------------------------------------------------------------------------------ main entry
+    def build(self, msas: List[MSA]) -> List[LocusResult]:
+        be = self.be
+        self._ids = [m.ids for m in msas]
+        self._pack(msas)
+        nodes: List[NodeRec] = []
+        results = [LocusResult(i, nodes, -1) for i in range(len(msas))]
+        frontier: List[int] = []
+        for i, m in enumerate(msas):
+            if i in self.bad:
+                results[i].error = self.bad[i]
+                continue
+            S, C = self.codes[i].shape
+            nodes.append(NodeRec(i, -1, 0, None, 0, C))
+            results[i].root = len(nodes) - 1
+            frontier.append(len(nodes) - 1)
+        failed = set(self.bad)
+        while frontier:
+            frontier = [ni for ni in frontier if nodes[ni].msa not in failed]
+            if not frontier:
+                break
+            self.counters["levels"] += 1
+            frontier = self._level(nodes, frontier, results, failed)
+        for r in results:
+            if r.error is None and r.root >= 0:
+                self._number_nodes(nodes, r.root)
+        self.nodes = nodes
+        return results
+
+    # ------------------------------------------------------------------------------------------------ one level
+    def _level(self, nodes, frontier, results, failed) -> List[int]:
+        be, L = self.be, self.L
+        tab, rowidx, total_cols, total_rows = self._view_table(nodes, frontier)
+        n = len(frontier)
+        self.counters["cells_all"] += int((tab[:, 5] * tab[:, 7]).sum())
+        d_views, d_rowidx = be.upload(tab), be.upload(rowidx)
+        work = self._mask_work(tab)
+        d_work = be.upload(work)
+        d_mask = be.zeros(4 * total_cols)
+        be.call("mprg_column_masks", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work),
+                work.shape[0], ROWS_PER_CHUNK, be.ptr(d_mask), be.stream)
+        d_maxrun, d_stack, d_ivflag = be.zeros(4 * total_cols), be.empty(16 * total_cols), be.zeros(8 * total_cols)
+        d_iv, d_niv, d_status = be.empty(12 * total_cols), be.empty(4 * n), be.empty(4 * n)
+        be.call("mprg_partition", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), n, be.ptr(d_mask), L,
+                be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv), be.ptr(d_status),
+                be.stream)
+        self.counters["launches"] += 2
+        mask = be.download(d_mask, np.uint32, total_cols)
+        n_iv = be.download(d_niv, np.int32, n)
+        status = be.download(d_status, np.int32, n)
+        iv = be.download(d_iv, np.int32, 3 * total_cols).reshape(-1, 3)
+
+        # consensus codes for all columns of the level (utils/seq_utils.py:228-238), vectorised
+        m = mask & ~np.uint32(BIT_N)
+        single = (m != 0) & ((m & (m - 1)) == 0) & ((m & BITS_IUPAC) == 0) & (m != BIT_GAP)
+        cons = np.full(total_cols, 255, np.uint8)
+        cons[single] = np.log2(m[single]).astype(np.uint8)
+        allgap = mask == BIT_GAP
+
+        next_frontier: List[int] = []
+        cluster_cands: List[int] = []      # positions j in frontier
+        dedupe_leaves: List[int] = []      # leaves whose rows must be grouped on the device
+        for j, ni in enumerate(frontier):
+            nd = nodes[ni]
+            if nd.msa in failed:
+                continue
+            co = int(tab[j, 8])
+            nd.keep_cols = ~allgap[co:co + nd.ncols]
+            nd.consensus = cons[co:co + nd.ncols]
+            if status[j]:
+                err = (SequenceCurationError("All sequences in this slice contained N. Redo sequence curation.")
+                       if status[j] & 2 else PartitioningError("Failed interval partitioning"))
+                results[nd.msa].error = err
+                failed.add(nd.msa)
+                continue
+            k = int(n_iv[j])
+            ivs = iv[co:co + k]
+            if k == 1 and ivs[0, 2] == 0:
+                nd.kind = "leaf"
+                if (nd.consensus == 255).any():
+                    dedupe_leaves.append(j)
+                else:
+                    nd.leaf_rows = None       # single sequence == the consensus string
+            elif k > 1 or nd.parent < 0:
+                nd.kind = "interval"
+                for a, b, _t in ivs:
+                    nodes.append(NodeRec(nd.msa, ni, nd.level, nd.rows, nd.col0 + int(a), int(b) - int(a) + 1))
+                    nd.children.append(len(nodes) - 1)
+                    next_frontier.append(len(nodes) - 1)
+            else:
+                cluster_cands.append(j)
+        if cluster_cands or dedupe_leaves:
+            next_frontier.extend(self._cluster_stage(nodes, frontier, tab, d_views, d_rowidx, cluster_cands,
+                                                     dedupe_leaves, results, failed))
+        return next_frontier
+
+    # ------------------------------------------------------------------------------------------------ clustering
+    def _cluster_stage(self, nodes, frontier, tab, d_views, d_rowidx, cands, leaves, results, failed) -> List[int]:
+        """A9-A14 for every single-non-match-interval view of the level (+ row grouping for non-trivial leaves)."""
+        be, K = self.be, self.L
+        sel = cands + leaves
+        # sub-table of the selected views with their own row offsets and ucodes regions
+        sub = tab[sel].copy()
+        pad_rows = (sub[:, 5] + 15) // 16 * 16
+        usize = sub[:, 7] * pad_rows
+        sub[:, 10] = np.cumsum(usize) - usize
+        sub[:, 9] = np.cumsum(sub[:, 5]) - sub[:, 5]
+        sub[:, 8] = np.cumsum(sub[:, 7]) - sub[:, 7]
+        tot_rows, tot_u, tot_cols = int(sub[:, 5].sum()), int(usize.sum()), int(sub[:, 7].sum())
+        d_sub = be.upload(sub)
+        d_ucodes, d_hash = be.empty(tot_u), be.empty(16 * tot_rows)
+        d_ulen, d_repu, d_repg = be.empty(4 * tot_rows), be.empty(4 * tot_rows), be.empty(4 * tot_rows)
+        be.call("mprg_ungap_dedupe", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), len(sel), be.ptr(d_ucodes),
+                be.ptr(d_hash), be.ptr(d_ulen), be.ptr(d_repu), be.ptr(d_repg), be.stream)
+        self.counters["launches"] += 1
+        ulen = be.download(d_ulen, np.int32, tot_rows)
+        rep_u = be.download(d_repu, np.int32, tot_rows)
+        rep_g = be.download(d_repg, np.int32, tot_rows)
+
+        new_nodes: List[int] = []
+        for q in range(len(cands), len(sel)):           # leaves: distinct ungapped rows in first-appearance order
+            nd = nodes[frontier[sel[q]]]
+            ro, S = int(sub[q, 9]), int(sub[q, 5])
+            nd.leaf_rows = np.nonzero(rep_u[ro:ro + S] == np.arange(S))[0]
+
+        # ---- per candidate: groups, early exits (A13, D <= 2), problem list
+        probs = []      # dicts
+        for q in range(len(cands)):
+            j = sel[q]
+            ni = frontier[j]
+            nd = nodes[ni]
+            ro, S = int(sub[q, 9]), int(sub[q, 5])
+            self.counters["cells_clustered"] += S * nd.ncols
+            ru, rg, ul = rep_u[ro:ro + S], rep_g[ro:ro + S], ulen[ro:ro + S]
+            is_rep = ru == np.arange(S)
+            nd.leaf_rows = np.nonzero(is_rep)[0]
+            n_unique_u = int(is_rep.sum())
+            n_unique_g = int((rg == np.arange(S)).sum())
+            # recursion_tree.py:538-556 / :475-494 — the clustering result is only used if all of these allow it
+            if nd.level + 1 >= self.max_nesting or n_unique_u <= 2 or n_unique_u < n_unique_g:
+                nd.kind = "leaf"
+                continue
+            long_reps = np.nonzero(is_rep & (ul >= K))[0]
+            D = len(long_reps)
+            if D <= 2:                                   # cluster_sequences.py:235-246: single cluster
+                nd.kind = "leaf"
+                continue
+            occ = (ul[long_reps] - K + 1).astype(np.int64)
+            probs.append(dict(q=q, ni=ni, nd=nd, S=S, ro=ro, ru=ru, ul=ul, long_reps=long_reps, D=D,
+                              occ_off=np.concatenate(([0], np.cumsum(occ))), T=int(occ.sum())))
+        if probs:
+            self._run_kmeans_problems(nodes, probs, sub, d_sub, d_rowidx, d_ucodes, d_ulen, tot_rows, tot_cols)
+            for p in probs:
+                new_nodes.extend(self._finish_cluster_node(nodes, p))
+        return new_nodes
+
+    def _uniforms(self, k: int):
+        if k not in self._uniform_cache:
+            n_trials = 2 + int(np.log(k))
+            u = self.be.random_sample(2, N_INIT * (1 + (k - 1) * n_trials))
+            self._uniform_cache[k] = self.be.upload(u)
+        return self._uniform_cache[k]
+
+    def _run_kmeans_problems(self, nodes, probs, sub, d_sub, d_rowidx, d_ucodes, d_ulen, tot_rows, tot_cols):
+        be, K = self.be, self.L
+        P = len(probs)
+        ptab = np.zeros((P, PF), np.int64)
+        seqrow, occ_offs = [], []
+        so = oo = to = fo = 0
+        for i, p in enumerate(probs):
+            cap = 16
+            while cap < 2 * p["T"]:
+                cap *= 2
+            ptab[i, 0], ptab[i, 1], ptab[i, 2], ptab[i, 3] = p["q"], p["D"], so, p["T"]
+            ptab[i, 4], ptab[i, 5], ptab[i, 6], ptab[i, 11] = to, cap, oo, fo
+            seqrow.append(p["long_reps"].astype(np.int32))
+            occ_offs.append(p["occ_off"].astype(np.int64))
+            so += p["D"]
+            oo += p["D"] + 1
+            to += 16 * cap
+            fo += _align(p["T"], 16)
+        d_seqrow, d_occ = be.upload(np.concatenate(seqrow)), be.upload(np.concatenate(occ_offs))
+        d_table, d_flag, d_V = be.empty(to), be.empty(fo), be.empty(4 * P)
+        d_ptab = be.upload(ptab)
+        be.call("mprg_kmer_dictionary", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(d_ucodes), be.ptr(d_ulen),
+                be.ptr(d_seqrow), be.ptr(d_occ), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), be.stream)
+        V = be.download(d_V, np.int32, P).astype(np.int64)
+        xo = wo = lo = 0
+        for i, p in enumerate(probs):
+            p["V"] = int(V[i])
+            ptab[i, 7], ptab[i, 8], ptab[i, 9], ptab[i, 10] = V[i], xo, wo, lo
+            xo += p["D"] * int(V[i])
+            wo += int(be.lib.mprg_kmeans_workspace_doubles(p["D"], int(V[i]), MAX_CLUSTERS, N_INIT))
+            lo += p["D"]
+        d_ptab = be.upload(ptab)
+        d_x, d_ws = be.zeros(8 * xo), be.empty(8 * wo)
+        d_labels, d_kmst, d_info = be.empty(4 * lo), be.zeros(4 * P), be.empty(32 * P)
+        be.call("mprg_kmer_counts", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(d_ucodes), be.ptr(d_ulen),
+                be.ptr(d_seqrow), be.ptr(d_occ), be.ptr(d_table), be.ptr(d_x), be.stream)
+        be.call("mprg_kmeans_prepare", be.ptr(d_ptab), P, be.ptr(d_x), be.ptr(d_ws), be.stream)
+        self.counters["launches"] += 3
+
+        # member labels / keys per row of the sub-table (cluster_sequences.py:252-274 loop state)
+        mlabel = np.full(tot_rows, -1, np.int32)
+        mkey = np.zeros(tot_rows, np.int32)
+        for p in probs:
+            S, ro, ru, ul = p["S"], p["ro"], p["ru"], p["ul"]
+            d_of_rep = np.full(S, -1, np.int64)
+            d_of_rep[p["long_reps"]] = np.arange(p["D"])
+            p["d_of_row"] = d_of_rep[ru]                     # distinct-sequence index of every row (-1: short)
+            member = p["d_of_row"] >= 0
+            order = np.lexsort((np.arange(S), p["d_of_row"]))
+            key = np.empty(S, np.int64)
+            key[order] = np.arange(S)
+            mkey[ro:ro + S] = key
+            p["assign"] = np.zeros(p["D"], np.int64)
+            p["num_clusters"] = 1
+            p["active"] = True
+            mlabel[ro:ro + S] = np.where(member, 0, -1)
+        d_mkey = be.upload(mkey)
+        d_scratch, d_further = be.empty(12 * tot_cols + 64), be.empty(4 * P)
+
+        def check(active_idx, k):
+            """cluster_further() for the listed problems with their current assignment (k clusters)."""
+            sub_ptab = ptab[active_idx]
+            d_sp = be.upload(sub_ptab)
+            d_ml = be.upload(mlabel)
+            be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp),
+                    len(active_idx), k, be.ptr(d_ml), be.ptr(d_mkey), be.ptr(d_scratch), be.ptr(d_further), be.stream)
+            self.counters["launches"] += 1
+            return be.download(d_further, np.int32, len(active_idx))
+
+        active = list(range(P))
+        fur = check(active, 1)
+        active = [i for i, f in zip(active, fur) if f]
+        k = 1
+        while active:
+            k += 1
+            still = []
+            for i in active:
+                p = probs[i]
+                p["num_clusters"] += 1
+                if p["num_clusters"] > MAX_CLUSTERS or p["num_clusters"] == p["D"]:
+                    continue                                 # cluster_sequences.py:258-261
+                still.append(i)
+            active = still
+            if not active:
+                break
+            sub_ptab = ptab[active]
+            d_sp = be.upload(sub_ptab)
+            nA = len(active)
+            d_st = be.zeros(4 * nA)
+            be.call("mprg_kmeans_restarts", be.ptr(d_sp), nA, k, N_INIT, be.ptr(self._uniforms(k)), be.ptr(d_ws),
+                    be.ptr(d_st), be.stream)
+            be.call("mprg_kmeans_select", be.ptr(d_sp), nA, k, N_INIT, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_labels),
+                    be.ptr(d_st), be.ptr(d_info), be.stream)
+            self.counters["launches"] += 2
+            st = be.download(d_st, np.int32, nA)
+            info = be.download(d_info, np.float64, 4 * nA).reshape(nA, 4)
+            labels_all = be.download(d_labels, np.int32, lo)
+            if st.any():
+                raise MprgError("KMeans hit an empty cluster (scikit-learn's relocation step is not implemented on "
+                                "the device); refusing to continue with a result that may differ from the reference")
+            nxt = []
+            for a, i in enumerate(active):
+                p = probs[i]
+                self.counters["fits"] += 1
+                self.counters["kmeans_bytes"] += 8 * p["D"] * p["V"] * (info[a, 1] * N_INIT + N_INIT)
+                p.setdefault("fits", []).append((p["D"], p["V"], k))
+                lab = labels_all[int(ptab[i, 10]):int(ptab[i, 10]) + p["D"]].astype(np.int64)
+                if int(info[a, 3]) < k:                      # cluster_sequences.py:267-273: revert and stop
+                    p["num_clusters"] -= 1
+                    continue
+                p["assign"] = lab
+                ro, S = p["ro"], p["S"]
+                member = p["d_of_row"] >= 0
+                mlabel[ro:ro + S] = np.where(member, lab[np.maximum(p["d_of_row"], 0)], -1)
+                nxt.append(i)
+            if not nxt:
+                break
+            fur = check(nxt, k)
+            active = [i for i, f in zip(nxt, fur) if f]
+
+    def _finish_cluster_node(self, nodes, p) -> List[int]:
+        """cluster_sequences.py:276-296 + recursion_tree.py:457-469, :558-572 on ids."""
+        nd: NodeRec = p["nd"]
+        D, k = p["D"], p["num_clusters"]
+        if k == 1 or k == D:
+            nd.kind = "leaf"
+            return []
+        m = nd.msa
+        view_rows = np.arange(self.meta[m][4]) if nd.rows is None else nd.rows
+        ids = self._ids[m]
+        row_ids = [ids[r] for r in view_rows]
+        S, ru, ul = p["S"], p["ru"], p["ul"]
+        clusters: List[List[str]] = [[] for _ in range(int(p["assign"].max()) + 1)]
+        if set(p["assign"].tolist()) != set(range(len(clusters))):
+            raise ValueError("Inconsistent cluster numbering")
+        rows_of_rep: Dict[int, List[int]] = {}
+        for i in range(S):
+            rows_of_rep.setdefault(int(ru[i]), []).append(i)
+        for d, rep in enumerate(p["long_reps"].tolist()):
+            clusters[int(p["assign"][d])].extend(row_ids[i] for i in rows_of_rep[rep])
+        short_reps = [r for r in sorted(rows_of_rep) if ul[r] < self.L]
+        clusters.extend([[row_ids[i] for i in rows_of_rep[r]] for r in short_reps])
+        first_id = row_ids[0]
+        chosen = next((c for c in clusters if first_id in c), None)
+        if chosen is None:
+            raise ValueError(f"Could not find {first_id} in any cluster")
+        rest = [c for c in clusters if c is not chosen]
+        chosen = list(chosen)
+        chosen.remove(first_id)
+        clusters = [[first_id] + chosen] + rest
+        assert sum(len(c) for c in clusters) == S, "Each input sequence should be in a cluster"
+        nd.kind = "cluster"
+        nd.level += 1                     # recursion_tree.py:459: the node itself sits one nesting level down
+        out = []
+        for c in clusters:
+            cset = set(c)
+            sel = np.asarray([view_rows[i] for i in range(S) if row_ids[i] in cset], dtype=np.int32)
+            nodes.append(NodeRec(m, p["ni"], nd.level, sel, nd.col0, nd.ncols))
+            nd.children.append(len(nodes) - 1)
+            out.append(len(nodes) - 1)
+        return out
+
+    # ------------------------------------------------------------------------------------------------ numbering
+    @staticmethod
+    def _number_nodes(nodes: List[NodeRec], root: int):
+        """Node ids in the reference's construction order: preorder (recursion_tree.py:48-55)."""
+        nid = 0
+        stack = [root]
+        while stack:
+            ni = stack.pop()
+            nodes[ni].node_id = nid
+            nid += 1
+            stack.extend(reversed(nodes[ni].children))
+
+
+# ----------------------------------------------------------------------------------------------------- emission
+def expand_sequences(seqs: List[str]) -> List[str]:
+    """utils/seq_utils.py:116-153 (order-preserving dedupe, drop rows with N, IUPAC expansion, dedupe)."""
+    import itertools
+    allowed = set(IUPAC) | {"N"}
+    for s in seqs:
+        if not set(s) <= allowed:
+            raise SequenceCurationError(f"A slice of a sequence has a disallowed base.\nSequence: {s}\nRedo sequence curation.\n")
+    out, seen, seen_in = [], set(), set()
+    for s in seqs:
+        if s in seen_in:
+            continue
+        seen_in.add(s)
+        if "N" in s:
+            continue
+        if set(s) <= set("ACGT"):
+            if s not in seen:
+                seen.add(s)
+                out.append(s)
+            continue
+        for combo in itertools.product(*(IUPAC[b] for b in s)):
+            e = "".join(combo)
+            if e not in seen:
+                seen.add(e)
+                out.append(e)
+    if not out:
+        raise SequenceCurationError(f"All sequences in this slice contained N. Redo sequence curation.\nSequences: {seqs}")
+    return out
+
+
+def leaf_sequences(engine: BatchEngine, nd: NodeRec) -> List[str]:
+    """The alleles a leaf emits (recursion_tree.py:272-274): distinct ungapped rows in order, expanded."""
+    if nd.leaf_rows is None:
+        return [decode(nd.consensus).tobytes().decode()]
+    codes = engine.codes[nd.msa]
+    rows = np.arange(codes.shape[0]) if nd.rows is None else nd.rows
+    block = codes[rows[nd.leaf_rows], nd.col0:nd.col0 + nd.ncols]
+    seqs = []
+    for r in block:
+        seqs.append(decode(r[r != CODE_GAP]).tobytes().decode())
+    return expand_sequences(seqs)
+
+
+def build_prg(engine: BatchEngine, res: LocusResult):
+    """PrgBuilder.build_prg (prg_builder.py:100-105) + the three traversals (recursion_tree.py:194-300).
+    Returns (prg string, {(start, end): node index})."""
+    nodes = res.nodes
+    out: List[str] = []
+    pos = 0
+    index: Dict[Tuple[int, int], int] = {}
+    site = 5
+    # iterative preorder with explicit "after child" actions
+    stack: List[tuple] = [("node", res.root)]
+    while stack:
+        item = stack.pop()
+        if item[0] == "text":
+            out.append(item[1])
+            pos += len(item[1])
+            continue
+        nd = nodes[item[1]]
+        if nd.kind == "interval":
+            for c in reversed(nd.children):
+                stack.append(("node", c))
+        elif nd.kind == "cluster":
+            s = site
+            site += 2
+            out.append(f" {s} ")
+            pos += len(out[-1])
+            nch = len(nd.children)
+            for i in reversed(range(nch)):
+                stack.append(("text", f" {s + 1 if i < nch - 1 else s} "))
+                stack.append(("node", nd.children[i]))
+        else:
+            seqs = leaf_sequences(engine, nd)
+            if len(seqs) == 1:
+                out.append(seqs[0])
+                index[(pos, pos + len(seqs[0]))] = item[1]
+                pos += len(seqs[0])
+            else:
+                s = site
+                site += 2
+                t = f" {s} "
+                out.append(t)
+                pos += len(t)
+                for i, q in enumerate(seqs):
+                    out.append(q)
+                    index[(pos, pos + len(q))] = item[1]
+                    pos += len(q)
+                    t = f" {s + 1 if i < len(seqs) - 1 else s} "
+                    out.append(t)
+                    pos += len(t)
+    return "".join(out), index, site
+
+
+def stored_alignment(engine: BatchEngine, nd: NodeRec, ids: List[str]):
+    """node.alignment of the reference: the node's sub-alignment without its all-gap columns
+    (recursion_tree.py:45 -> utils/seq_utils.py:193-216).  Column selection = the device's all-gap mask."""
+    codes = engine.codes[nd.msa]
+    rows = np.arange(codes.shape[0]) if nd.rows is None else nd.rows
+    block = codes[rows, nd.col0:nd.col0 + nd.ncols][:, nd.keep_cols]
+    return [ids[r] for r in rows], decode(block)
+
+
+def tree_dump(engine: BatchEngine, res: LocusResult, ids: List[str]) -> list:
+    """Flat preorder dump (same shape as oracle.from_msa_oracle.tree_dump) for tree-equality checks."""
+    out = []
+    nodes = res.nodes
+    stack = [res.root]
+    while stack:
+        ni = stack.pop()
+        nd = nodes[ni]
+        rids, block = stored_alignment(engine, nd, ids)
+        out.append(dict(id=nd.node_id, kind=nd.kind, level=nd.level,
+                        parent=None if nd.parent < 0 else nodes[nd.parent].node_id,
+                        rows=[[i, r.tobytes().decode()] for i, r in zip(rids, block)],
+                        children=[nodes[c].node_id for c in nd.children]))
+        stack.extend(reversed(nd.children))
+    return out

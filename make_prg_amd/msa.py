@@ -1,0 +1,207 @@
+"""Alignment container of the MI355X path.
+
+The reference's boundary type is `make_prg.MSA = Bio.AlignIO.MultipleSeqAlignment` (make_prg/__init__.py:7-9).
+This module provides the part of that contract the from_msa path uses: len(), iteration over
+records with .id/.seq/.description, get_alignment_length(), msa[i], msa[:, a:b], MSA(records),
+format(msa, "fasta") — backed by one uint8 rows x columns matrix (ASCII bytes on the host; 1-byte symbol codes on
+the device, see include/mprg.h), so that slicing is a view and packing for the GPU is one table lookup.
+"""
+import gzip
+import hashlib
+import random
+from collections import Counter
+from io import StringIO
+from typing import Iterable, List, Optional, Sequence, Union
+
+import numpy as np
+
+ALPHABET = b"ACGT-RYKMSWN"
+CODE_GAP, CODE_N = 4, 11
+_ENC = np.full(256, 255, np.uint8)
+for _i, _b in enumerate(ALPHABET):
+    _ENC[_b] = _i
+_DEC = np.frombuffer(ALPHABET + b"?" * (256 - len(ALPHABET)), dtype=np.uint8)
+
+
+def encode(ascii_matrix: np.ndarray) -> np.ndarray:
+    """ASCII bytes -> device symbol codes; 255 marks a byte outside ACGT-RYKMSWN."""
+    return _ENC[ascii_matrix]
+
+
+def decode(codes: np.ndarray) -> np.ndarray:
+    return _DEC[codes]
+
+
+class Record:
+    """One row: what the path reads from a Bio.SeqRecord (id, seq, description)."""
+    __slots__ = ("id", "description", "_data", "name")
+
+    def __init__(self, seq: Union[str, bytes, np.ndarray], id: str = "<unknown id>", description: str = "<unknown description>",
+                 name: Optional[str] = None):
+        if isinstance(seq, np.ndarray):
+            self._data = seq
+        else:
+            self._data = np.frombuffer(seq.encode() if isinstance(seq, str) else bytes(seq), dtype=np.uint8)
+        self.id = id
+        self.description = description
+        self.name = id if name is None else name
+
+    @property
+    def seq(self) -> str:
+        return self._data.tobytes().decode()
+
+    def __len__(self):
+        return int(self._data.shape[0])
+
+    def __iter__(self):
+        return iter(self.seq)
+
+    def __getitem__(self, item):
+        if isinstance(item, slice):
+            return Record(self._data[item], self.id, self.description, self.name)
+        return chr(self._data[item])
+
+
+def _fasta_title(rid: str, desc: str) -> str:
+    # Bio.SeqIO FastaWriter title rule
+    if desc and desc.split(None, 1)[0] == rid:
+        return desc
+    if desc:
+        return f"{rid} {desc}"
+    return rid
+
+
+class MSA:
+    def __init__(self, records: Iterable[Record] = (), *, _data=None, _ids=None, _descs=None):
+        if _data is not None:
+            self.data, self.ids, self.descriptions = _data, list(_ids), list(_descs)
+            return
+        records = list(records)
+        if records:
+            lengths = {len(r) for r in records}
+            if len(lengths) != 1:
+                raise ValueError("Sequences must all be the same length")
+            self.data = np.stack([r._data for r in records]).astype(np.uint8, copy=False)
+        else:
+            self.data = np.zeros((0, 0), np.uint8)
+        self.ids = [r.id for r in records]
+        self.descriptions = [r.description for r in records]
+
+    @classmethod
+    def from_strings(cls, seqs: Sequence[str], ids: Optional[Sequence[str]] = None, descriptions=None) -> "MSA":
+        ids = [f"s{i}" for i in range(len(seqs))] if ids is None else list(ids)
+        descs = [""] * len(seqs) if descriptions is None else list(descriptions)
+        return cls([Record(s, i, d) for s, i, d in zip(seqs, ids, descs)])
+
+    def __len__(self):
+        return int(self.data.shape[0])
+
+    def get_alignment_length(self) -> int:
+        return int(self.data.shape[1]) if len(self) else 0
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def __getitem__(self, index):
+        if isinstance(index, (int, np.integer)):
+            return Record(self.data[index], self.ids[index], self.descriptions[index])
+        if isinstance(index, slice):
+            return MSA(_data=self.data[index], _ids=self.ids[index], _descs=self.descriptions[index])
+        rows, cols = index
+        if isinstance(rows, (int, np.integer)):
+            return self[rows][cols]
+        sub = self.data[rows]
+        if isinstance(cols, (int, np.integer)):
+            return sub[:, cols].tobytes().decode()
+        return MSA(_data=sub[:, cols], _ids=self.ids[rows], _descs=self.descriptions[rows])
+
+    def rows_as_strings(self) -> List[str]:
+        return [self.data[i].tobytes().decode() for i in range(len(self))]
+
+    def __format__(self, fmt):
+        if fmt != "fasta":
+            raise ValueError(f"unsupported format {fmt}")
+        out = []
+        for i in range(len(self)):
+            out.append(f">{_fasta_title(self.ids[i], self.descriptions[i])}\n")
+            s = self.data[i].tobytes().decode()
+            out.extend(s[p:p + 60] + "\n" for p in range(0, len(s), 60))
+        return "".join(out)
+
+    def format(self, fmt):
+        return self.__format__(fmt)
+
+
+# ---------------------------------------------------------------------------------------------------- ingest (A0)
+def _parse_fasta(text: str):
+    title, chunks = None, []
+    for line in text.splitlines():
+        if line.startswith(">"):
+            if title is not None:
+                yield title, "".join(chunks)
+            title, chunks = line[1:].rstrip(), []
+        elif title is not None:
+            chunks.append("".join(line.split()))
+    if title is not None:
+        yield title, "".join(chunks)
+
+
+def read_fasta_alignment(text: str) -> MSA:
+    """AlignIO.read(handle, "fasta") behaviour the path relies on (utils/io_utils.py:17-31)."""
+    recs = []
+    for title, seq in _parse_fasta(text):
+        words = title.split(None, 1)
+        recs.append(Record(seq, words[0] if words else "", title))
+    if not recs:
+        raise ValueError("No records found in handle")
+    return MSA(recs)
+
+
+def _majority_consensus(upper: np.ndarray) -> np.ndarray:
+    """utils/seq_utils.py:246-290: one Random(sha256(rows)) draw per column; choice among the most frequent
+    non-gap non-N residues in first-seen order, or among ACGT if the column has none."""
+    rng = random.Random()
+    rng.seed(hashlib.sha256(upper.tobytes()).digest())
+    S, C = upper.shape
+    out = np.empty(C, np.uint8)
+    gap, n = ord("-"), ord("N")
+    const_col = (upper == upper[0:1]).all(axis=0)
+    for c in range(C):
+        col = upper[:, c]
+        if const_col[c] and col[0] != gap and col[0] != n:
+            out[c] = ord(rng.choice([chr(col[0])]))
+            continue
+        counts = Counter(chr(x) for x in col.tolist() if x != gap and x != n)
+        if not counts:
+            out[c] = ord(rng.choice("ACGT"))
+            continue
+        top = max(counts.values())
+        out[c] = ord(rng.choice([r for r, k in counts.items() if k == top]))
+    return out
+
+
+def load_alignment_text(text: str) -> MSA:
+    """utils/io_utils.py:17-49: parse, upper-case, overwrite every N with its column's majority-consensus base."""
+    msa = read_fasta_alignment(text)
+    data = msa.data.copy()
+    lower = (data >= ord("a")) & (data <= ord("z"))
+    data[lower] -= 32
+    cons = _majority_consensus(data)
+    is_n = data == ord("N")
+    if is_n.any():
+        data[is_n] = np.broadcast_to(cons, data.shape)[is_n]
+    return MSA(_data=data, _ids=msa.ids, _descs=msa.descriptions)
+
+
+def load_alignment_file(msa_file, alignment_format: str = "fasta") -> MSA:
+    if alignment_format != "fasta":
+        raise ValueError("only the fasta alignment format is supported by the MI355X path")
+    if isinstance(msa_file, StringIO):
+        return load_alignment_text(msa_file.getvalue())
+    path = str(msa_file)
+    if path.endswith(".gz"):
+        with gzip.open(path, "rt") as fh:
+            return load_alignment_text(fh.read())
+    with open(path) as fh:
+        return load_alignment_text(fh.read())

@@ -1,0 +1,58 @@
+"""TEST-ONLY stand-in for make_prg_amd.backend.HipBackend.
+
+Compiles make_prg_amd/csrc/mprg_api.hip with g++ -DMPRG_CPU_EMU (see csrc/mprg_platform.h): the same kernel bodies,
+one workgroup at a time, PAR_FOR as a plain loop, "device" buffers as NumPy arrays.  It lets the GPU-less build
+container check the kernel LOGIC and the host engine against the oracle.  The product never imports this module;
+`-m gpu` tests and everything under make_prg_amd/ use the HIP library only.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from make_prg_amd.backend import _Base, bind
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SRC_DIR = os.path.join(ROOT, "make_prg_amd", "csrc")
+LIB = os.path.join(HERE, "_build", "libmprg_emu.so")
+
+
+def build_emu(force=False) -> str:
+    srcs = [os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR)] + [os.path.join(ROOT, "include", "mprg.h")]
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-DMPRG_CPU_EMU", "-O2", "-ffp-contract=off", "-mfma",
+                               "-fPIC", "-shared", "-Wno-unused-function", os.path.join(SRC_DIR, "mprg_api.hip"), "-o", LIB])
+    return LIB
+
+
+class EmuBackend(_Base):
+    name = "cpu-emulation(test-only)"
+
+    def __init__(self):
+        self.lib = bind(ctypes.CDLL(build_emu()))
+        self.stream = None
+        self.n_cus = 1
+
+    def empty(self, nbytes):
+        return np.full(max(int(nbytes), 16), 0xA5, np.uint8)   # poison: catches reads of unwritten scratch
+
+    def zeros(self, nbytes):
+        return np.zeros(max(int(nbytes), 16), np.uint8)
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()
+        return a if a.size else self.empty(16)
+
+    def download(self, buf, dtype, count):
+        nbytes = int(count) * np.dtype(dtype).itemsize
+        return buf[:nbytes].copy().view(dtype)
+
+    def ptr(self, buf):
+        return buf.ctypes.data
+
+    def synchronize(self):
+        pass

@@ -1,0 +1,43 @@
+"""Drive the three KMeans entry points of the C ABI directly on given count matrices (any backend)."""
+import numpy as np
+
+PF = 12
+
+
+def run_kmeans_fits(be, fits, n_init=10):
+    out = []
+    groups = {}
+    for idx, f in enumerate(fits):
+        groups.setdefault(f["k"], []).append(idx)
+    results = [None] * len(fits)
+    for k, idxs in groups.items():
+        P = len(idxs)
+        ptab = np.zeros((P, PF), np.int64)
+        xs = []
+        xo = wo = lo = 0
+        for i, idx in enumerate(idxs):
+            f = fits[idx]
+            D, V = f["shape"]
+            X = np.frombuffer(bytes.fromhex(f["counts_i16_hex"]), dtype="<i2").reshape(D, V).astype(np.float64)
+            xs.append(X.reshape(-1))
+            ptab[i, 1], ptab[i, 7], ptab[i, 8], ptab[i, 9], ptab[i, 10] = D, V, xo, wo, lo
+            xo += D * V
+            wo += int(be.lib.mprg_kmeans_workspace_doubles(D, V, 10, n_init))
+            lo += D
+        d_p, d_x, d_ws = be.upload(ptab), be.upload(np.concatenate(xs)), be.empty(8 * wo)
+        d_lab, d_st, d_info = be.empty(4 * lo), be.zeros(4 * P), be.empty(32 * P)
+        n_trials = 2 + int(np.log(k))
+        d_u = be.upload(be.random_sample(2, n_init * (1 + (k - 1) * n_trials)))
+        be.call("mprg_kmeans_prepare", be.ptr(d_p), P, be.ptr(d_x), be.ptr(d_ws), be.stream)
+        be.call("mprg_kmeans_restarts", be.ptr(d_p), P, k, n_init, be.ptr(d_u), be.ptr(d_ws), be.ptr(d_st), be.stream)
+        be.call("mprg_kmeans_select", be.ptr(d_p), P, k, n_init, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_lab), be.ptr(d_st),
+                be.ptr(d_info), be.stream)
+        labels = be.download(d_lab, np.int32, lo)
+        info = be.download(d_info, np.float64, 4 * P).reshape(P, 4)
+        st = be.download(d_st, np.int32, P)
+        for i, idx in enumerate(idxs):
+            D = fits[idx]["shape"][0]
+            o = int(ptab[i, 10])
+            results[idx] = dict(labels=labels[o:o + D].tolist(), inertia_hex=float(info[i, 0]).hex(),
+                                n_iter=int(info[i, 1]), status=int(st[i]))
+    return results

@@ -1,0 +1,25 @@
+"""Host engine + kernel LOGIC on the CPU emulation build of the kernel source (tests/emu) against the golden
+vectors.  This is not the product path (the product path is HIP only, tests/test_gpu_parity.py); it is here so the
+host recursion driver and every kernel body are exercised in the GPU-less container."""
+import numpy as np
+import pytest
+
+from tests.emu.backend import EmuBackend
+from tests import parity_common as pc
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return EmuBackend()
+
+
+def test_integration_cases(emu, golden_integration):
+    assert pc.check_integration(emu, golden_integration) >= 30
+
+
+def test_synthetic_b(emu, golden_synthetic):
+    assert pc.check_synthetic(emu, golden_synthetic, configs=("B",)) == 40
+
+
+def test_synthetic_c_and_deep(emu, golden_synthetic):
+    assert pc.check_synthetic(emu, golden_synthetic, configs=("C", "Dsmall")) == 7

@@ -1,0 +1,54 @@
+"""Parity tests proper: the HIP path (libmprg_hip.so through the C ABI, device buffers in HBM) against the golden
+vectors of the real reference and against the oracle.  Run on the MI355X box with `-m gpu`."""
+import numpy as np
+import pytest
+
+from tests import parity_common as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from make_prg_amd.backend import HipBackend
+    return HipBackend(0)          # raises if the library or the GPU is missing: no fallback
+
+
+def test_library_is_the_hip_build(hip):
+    assert b"hip gfx950" in hip.lib.mprg_version()
+    assert hip.n_cus >= 200
+
+
+def test_integration_cases(hip, golden_integration):
+    assert pc.check_integration(hip, golden_integration) >= 30
+
+
+def test_synthetic_config_b(hip, golden_synthetic):
+    assert pc.check_synthetic(hip, golden_synthetic, configs=("B",)) == 40
+
+
+def test_synthetic_config_c_and_deep(hip, golden_synthetic):
+    assert pc.check_synthetic(hip, golden_synthetic, configs=("C", "Dsmall")) == 7
+
+
+def test_kmeans_known_answers(hip, golden_kmeans):
+    """The device KMeans against the scikit-learn answers captured from the reference run (labels, inertia bits)."""
+    from tests.kmeans_direct import run_kmeans_fits
+    fits = golden_kmeans["fits"]
+    got = run_kmeans_fits(hip, fits)
+    for g, f in zip(got, fits):
+        assert g["labels"] == f["labels"]
+        assert g["inertia_hex"] == f["inertia"]
+        assert g["n_iter"] == f["n_iter"]
+
+
+def test_batch_of_fresh_seeds_against_oracle(hip):
+    from make_prg_amd.utils.synthetic import synth_config_fasta
+    texts = [synth_config_fasta("B", s) for s in range(100, 148)]
+    pc.check_vs_oracle(hip, texts)
+
+
+def test_edge_cases_against_oracle(hip):
+    from tests.edge_cases import EDGE_FASTAS
+    for N, L, texts in EDGE_FASTAS:
+        pc.check_vs_oracle(hip, texts, N, L)
