@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — MSAs/sec of the from_msa hot path on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path (whole recursion forest + PRG string emission) over one batch of synthetic
+config-C alignments (the 30k-gene pan-genome shape of BASELINE.json: ~100 seqs x 1-3 kb, generator in
+make_prg_amd/utils/synthetic.py) that is already resident in HBM.  Each rank owns `--batch` alignments (weak
+scaling: the directory of MSAs shards with no data-path collective).  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def _gen(seed):
+    from make_prg_amd.msa import load_alignment_text
+    from make_prg_amd.utils.synthetic import synth_config_fasta
+    return load_alignment_text(synth_config_fasta("C", seed))
+
+
+def _oracle_one(seed):
+    import oracle.from_msa_oracle as orc
+    from make_prg_amd.utils.synthetic import synth_config_fasta
+    prg, b, root = orc.build_locus_from_text(synth_config_fasta("C", seed), 5, 7)
+    return len(prg)
+
+
+def make_batch(seeds, procs):
+    if procs > 1 and len(seeds) >= 64:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(procs) as pool:
+            return pool.map(_gen, seeds, chunksize=8)
+    return [_gen(s) for s in seeds]
+
+
+def cpu_baseline(n_sample, procs):
+    """The oracle (CPU restatement of the reference path, `port`) on a bounded sample of the same workload."""
+    import multiprocessing as mp
+    import oracle.from_msa_oracle as orc
+    orc.build_kmeans_lib()
+    seeds = list(range(1_000_000, 1_000_000 + n_sample))       # same generator/config, disjoint seeds
+    with mp.get_context("fork").Pool(procs) as pool:
+        pool.map(_oracle_one, seeds[:procs], chunksize=1)       # untimed: worker start-up, first-touch, imports
+        t0 = time.perf_counter()
+        pool.map(_oracle_one, seeds, chunksize=1)
+        dt = time.perf_counter() - t0
+    return n_sample / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1024, help="alignments per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gen-procs", type=int, default=0, help="processes for input generation (0 = auto; use 1 under rocprofv3)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ncpu = os.cpu_count() or 1
+
+    # CPU baseline first (rank 0, single-GPU runs only), before the GPU is initialised: it forks worker processes
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        n = args.cpu_sample or max(ncpu * 6, 48)
+        v, dt = cpu_baseline(n, ncpu)
+        cpu = dict(value=round(v, 3), unit="MSAs/s", cores=ncpu, kind="port",
+                   sample=f"{n} config-C alignments (seeds 1000000..), oracle/ (Python + C KMeans restatement of the "
+                          f"reference path), {ncpu} worker processes, one alignment per task, {dt:.1f}s wall")
+
+    procs_gen = args.gen_procs or max(1, min(ncpu // max(world, 1), 16))
+    seeds = [rank * 100_000 + i for i in range(args.batch)]
+    msas = make_batch(seeds, procs_gen)
+
+    import torch
+    import torch.distributed as dist
+    from make_prg_amd.backend import HipBackend
+    from make_prg_amd.engine import BatchEngine, build_prg
+
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    be = HipBackend(local_rank)
+    eng = BatchEngine(be, max_nesting=5, min_match_length=7)
+    t_ing = time.perf_counter()
+    eng.load(msas)                                   # ingest: encode + upload; inputs are now resident in HBM
+    t_ing = time.perf_counter() - t_ing
+
+    def step():
+        res = eng.run()
+        n_ok = 0
+        chars = 0
+        for r in res:
+            if r.error is None:
+                prg, _, _ = build_prg(eng, r)
+                chars += len(prg)
+                n_ok += 1
+        return n_ok, chars
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    be.profile = {}
+    for key in eng.counters:
+        eng.counters[key] = 0 if key != "arena_bytes" else eng.counters[key]
+    barrier()
+    t0 = time.perf_counter()
+    n_ok = 0
+    for _ in range(args.steps):
+        n_ok, chars = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = be.profile_summary()
+    be.profile = None
+
+    t = torch.tensor([dt], dtype=torch.float64, device=be.device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    total_msas = args.batch * world * args.steps
+    value = total_msas / dt_max
+
+    if rank == 0:
+        dev_ms = sum(v["ms"] for v in prof.values())
+        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        name, d = dom
+        launches = d["calls"]
+        achieved = (d["bytes"] / max(d["ms"], 1e-9)) * 1e-6          # bytes/ms -> GB/s
+        roof = dict(bound="hbm", kernel=name, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
+                    avg_launch_ms=round(d["ms"] / max(launches, 1), 4), launches=launches,
+                    algorithmic_bytes_per_launch=round(d["bytes"] / max(launches, 1), 1))
+        kernels = {k: dict(ms=round(v["ms"], 3), calls=v["calls"],
+                           GBps=round((v["bytes"] / max(v["ms"], 1e-9)) * 1e-6, 3) if v["bytes"] else None)
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        out = {
+            "metric": "MSAs/sec (from_msa, whole node) on 30k-gene pan-genome",
+            "value": round(value, 3), "unit": "MSAs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 (+f64 KMeans)", "data": "synthetic",
+            "config": {"workload": "C: 30k-gene pan-genome shape (S~N(100,20) in [20,300] rows x 1000-3000 cols, "
+                                   "SURVEY.md §8d generator), -N 5 -L 7; one step = one resident batch per GPU",
+                       "batch_per_gpu": args.batch, "parallelism": f"shard{world}",
+                       "step_includes": "recursion forest on device + host control + PRG string emission",
+                       "ingest_s_excluded": round(t_ing, 3), "device_ms_per_step": round(dev_ms / args.steps, 3),
+                       "levels": eng.counters["levels"] / args.steps, "launches_per_step": eng.counters["launches"] / args.steps,
+                       "kmeans_fits_per_step": eng.counters["fits"] / args.steps,
+                       "B_alg_bytes_per_step": (eng.counters["cells_all"] + eng.counters["cells_clustered"]
+                                                + eng.counters["kmeans_bytes"]) / args.steps,
+                       "kernels": kernels},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

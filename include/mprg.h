@@ -99,8 +99,8 @@ int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int
  *   mprg_kmeans_restarts: per (problem, restart): k-means++ from `uniforms` + Elkan iterations.
  *   mprg_kmeans_select  : per problem: best restart by the reference's rule, then predict().
  * uniforms_host: n_init * (1 + (k-1)*(2+int(ln k))) doubles of numpy RandomState(2).random_sample (host pointer,
- * copied by the call).  labels int32 at prob[LABEL_OFF]; km_status int32[n_probs]; km_info double[4*n_probs]
- * = {inertia, n_iter, best restart, n distinct labels}.
+ * copied by the call).  labels int32 at prob[LABEL_OFF]; km_status int32[n_probs]; km_info double[8*n_probs]
+ * = {inertia, n_iter of the best restart, best restart, n distinct labels, total Elkan iterations, -, -, -}.
  * Workspace size per problem (doubles): mprg_kmeans_workspace_doubles(D, V, k_max, n_init). */
 int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_init);
 int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, void *stream);

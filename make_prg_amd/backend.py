@@ -50,10 +50,31 @@ def bind(lib):
 class _Base:
     """Shared call helper: every kernel entry point returns 0 or raises with the library's message."""
 
-    def call(self, name, *args):
+    profile = None   # set to a dict to collect per-entry-point device time (HIP events on the launch stream)
+
+    def call(self, name, *args, work: float = 0.0):
+        """Enqueue one C-ABI entry point.  `work` = algorithmic bytes of this launch (roofline accounting)."""
+        ev = self._event_pair() if self.profile is not None else None
+        if ev:
+            ev[0].record()
         rc = getattr(self.lib, name)(*args)
+        if ev:
+            ev[1].record()
+            self.profile.setdefault(name, []).append((ev[0], ev[1], float(work)))
         if rc != 0:
             raise MprgError(f"{name} failed ({rc}): {self.lib.mprg_last_error().decode()}")
+
+    def _event_pair(self):
+        return None
+
+    def profile_summary(self):
+        """{entry point: dict(calls, ms, bytes)} from the recorded events (synchronises)."""
+        self.synchronize()
+        out = {}
+        for name, evs in (self.profile or {}).items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+            out[name] = dict(calls=len(evs), ms=ms, bytes=sum(w for _, _, w in evs))
+        return out
 
     def random_sample(self, seed: int, n: int) -> np.ndarray:
         out = np.empty(n, np.float64)
@@ -104,3 +125,7 @@ class HipBackend(_Base):
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
+
+    def _event_pair(self):
+        # torch.cuda.Event wraps hipEvent_t; kernels are enqueued on torch's current stream, the one these record on
+        return (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))

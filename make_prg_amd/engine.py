@@ -154,10 +154,21 @@ class BatchEngine:
         return work
 
     # ------------------------------------------------------------------------------------------------ main entry
-    def build(self, msas: List[MSA]) -> List[LocusResult]:
-        be = self.be
+    def load(self, msas: List[MSA]):
+        """Ingest: encode + lay out + upload the batch; afterwards the alignments are resident in HBM."""
         self._ids = [m.ids for m in msas]
+        self._msas = msas
         self._pack(msas)
+        self.be.synchronize()
+
+    def build(self, msas: List[MSA]) -> List[LocusResult]:
+        self.load(msas)
+        return self.run()
+
+    def run(self) -> List[LocusResult]:
+        """The hot path on the resident batch: the whole recursion forest, level by level."""
+        be = self.be
+        msas = self._msas
         nodes: List[NodeRec] = []
         results = [LocusResult(i, nodes, -1) for i in range(len(msas))]
         frontier: List[int] = []
@@ -193,12 +204,12 @@ class BatchEngine:
         d_work = be.upload(work)
         d_mask = be.zeros(4 * total_cols)
         be.call("mprg_column_masks", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work),
-                work.shape[0], ROWS_PER_CHUNK, be.ptr(d_mask), be.stream)
+                work.shape[0], ROWS_PER_CHUNK, be.ptr(d_mask), be.stream, work=float((tab[:, 5] * tab[:, 7]).sum()))
         d_maxrun, d_stack, d_ivflag = be.zeros(4 * total_cols), be.empty(16 * total_cols), be.zeros(8 * total_cols)
         d_iv, d_niv, d_status = be.empty(12 * total_cols), be.empty(4 * n), be.empty(4 * n)
         be.call("mprg_partition", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), n, be.ptr(d_mask), L,
                 be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv), be.ptr(d_status),
-                be.stream)
+                be.stream, work=float((tab[:, 5] * tab[:, 7]).sum()))
         self.counters["launches"] += 2
         mask = be.download(d_mask, np.uint32, total_cols)
         n_iv = be.download(d_niv, np.int32, n)
@@ -266,7 +277,8 @@ class BatchEngine:
         d_ucodes, d_hash = be.empty(tot_u), be.empty(16 * tot_rows)
         d_ulen, d_repu, d_repg = be.empty(4 * tot_rows), be.empty(4 * tot_rows), be.empty(4 * tot_rows)
         be.call("mprg_ungap_dedupe", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), len(sel), be.ptr(d_ucodes),
-                be.ptr(d_hash), be.ptr(d_ulen), be.ptr(d_repu), be.ptr(d_repg), be.stream)
+                be.ptr(d_hash), be.ptr(d_ulen), be.ptr(d_repu), be.ptr(d_repg), be.stream,
+                work=2.0 * float((sub[:, 5] * sub[:, 7]).sum()))
         self.counters["launches"] += 1
         ulen = be.download(d_ulen, np.int32, tot_rows)
         rep_u = be.download(d_repu, np.int32, tot_rows)
@@ -349,7 +361,7 @@ class BatchEngine:
             lo += p["D"]
         d_ptab = be.upload(ptab)
         d_x, d_ws = be.zeros(8 * xo), be.empty(8 * wo)
-        d_labels, d_kmst, d_info = be.empty(4 * lo), be.zeros(4 * P), be.empty(32 * P)
+        d_labels, d_kmst, d_info = be.empty(4 * lo), be.zeros(4 * P), be.empty(64 * P)
         be.call("mprg_kmer_counts", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(d_ucodes), be.ptr(d_ulen),
                 be.ptr(d_seqrow), be.ptr(d_occ), be.ptr(d_table), be.ptr(d_x), be.stream)
         be.call("mprg_kmeans_prepare", be.ptr(d_ptab), P, be.ptr(d_x), be.ptr(d_ws), be.stream)
@@ -405,13 +417,14 @@ class BatchEngine:
             d_sp = be.upload(sub_ptab)
             nA = len(active)
             d_st = be.zeros(4 * nA)
+            km_work = [0.0]
             be.call("mprg_kmeans_restarts", be.ptr(d_sp), nA, k, N_INIT, be.ptr(self._uniforms(k)), be.ptr(d_ws),
                     be.ptr(d_st), be.stream)
             be.call("mprg_kmeans_select", be.ptr(d_sp), nA, k, N_INIT, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_labels),
                     be.ptr(d_st), be.ptr(d_info), be.stream)
             self.counters["launches"] += 2
             st = be.download(d_st, np.int32, nA)
-            info = be.download(d_info, np.float64, 4 * nA).reshape(nA, 4)
+            info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
             labels_all = be.download(d_labels, np.int32, lo)
             if st.any():
                 raise MprgError("KMeans hit an empty cluster (scikit-learn's relocation step is not implemented on "
@@ -420,7 +433,9 @@ class BatchEngine:
             for a, i in enumerate(active):
                 p = probs[i]
                 self.counters["fits"] += 1
-                self.counters["kmeans_bytes"] += 8 * p["D"] * p["V"] * (info[a, 1] * N_INIT + N_INIT)
+                kb = 8.0 * p["D"] * p["V"] * (info[a, 4] + N_INIT)
+                self.counters["kmeans_bytes"] += kb
+                km_work[0] += kb
                 p.setdefault("fits", []).append((p["D"], p["V"], k))
                 lab = labels_all[int(ptab[i, 10]):int(ptab[i, 10]) + p["D"]].astype(np.int64)
                 if int(info[a, 3]) < k:                      # cluster_sequences.py:267-273: revert and stop
@@ -431,6 +446,9 @@ class BatchEngine:
                 member = p["d_of_row"] >= 0
                 mlabel[ro:ro + S] = np.where(member, lab[np.maximum(p["d_of_row"], 0)], -1)
                 nxt.append(i)
+            if be.profile is not None and be.profile.get("mprg_kmeans_restarts"):
+                a0, a1, _ = be.profile["mprg_kmeans_restarts"][-1]       # algorithmic bytes known only after the fit
+                be.profile["mprg_kmeans_restarts"][-1] = (a0, a1, km_work[0])
             if not nxt:
                 break
             fur = check(nxt, k)

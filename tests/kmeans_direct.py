@@ -25,7 +25,7 @@ def run_kmeans_fits(be, fits, n_init=10):
             wo += int(be.lib.mprg_kmeans_workspace_doubles(D, V, 10, n_init))
             lo += D
         d_p, d_x, d_ws = be.upload(ptab), be.upload(np.concatenate(xs)), be.empty(8 * wo)
-        d_lab, d_st, d_info = be.empty(4 * lo), be.zeros(4 * P), be.empty(32 * P)
+        d_lab, d_st, d_info = be.empty(4 * lo), be.zeros(4 * P), be.empty(64 * P)
         n_trials = 2 + int(np.log(k))
         d_u = be.upload(be.random_sample(2, n_init * (1 + (k - 1) * n_trials)))
         be.call("mprg_kmeans_prepare", be.ptr(d_p), P, be.ptr(d_x), be.ptr(d_ws), be.stream)
@@ -33,7 +33,7 @@ def run_kmeans_fits(be, fits, n_init=10):
         be.call("mprg_kmeans_select", be.ptr(d_p), P, k, n_init, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_lab), be.ptr(d_st),
                 be.ptr(d_info), be.stream)
         labels = be.download(d_lab, np.int32, lo)
-        info = be.download(d_info, np.float64, 4 * P).reshape(P, 4)
+        info = be.download(d_info, np.float64, 8 * P).reshape(P, 8)
         st = be.download(d_st, np.int32, P)
         for i, idx in enumerate(idxs):
             D = fits[idx]["shape"][0]
