@@ -165,10 +165,14 @@ class BatchEngine:
         self.load(msas)
         return self.run()
 
-    def run(self) -> List[LocusResult]:
-        """The hot path on the resident batch: the whole recursion forest, level by level."""
+    def run(self, root_level: int = 0, root_is_tree_root: bool = True) -> List[LocusResult]:
+        """The hot path on the resident batch: the whole recursion forest, level by level.
+        root_level / root_is_tree_root: re-entry of NodeFactory.build below an existing parent
+        (LeafNode._update_leaf, recursion_tree.py:374-376) starts at the parent's nesting level and does not force a
+        MultiIntervalNode."""
         be = self.be
         msas = self._msas
+        self._root_forced = root_is_tree_root
         nodes: List[NodeRec] = []
         results = [LocusResult(i, nodes, -1) for i in range(len(msas))]
         frontier: List[int] = []
@@ -177,7 +181,7 @@ class BatchEngine:
                 results[i].error = self.bad[i]
                 continue
             S, C = self.codes[i].shape
-            nodes.append(NodeRec(i, -1, 0, None, 0, C))
+            nodes.append(NodeRec(i, -1, root_level, None, 0, C))
             results[i].root = len(nodes) - 1
             frontier.append(len(nodes) - 1)
         failed = set(self.bad)
@@ -194,27 +198,40 @@ class BatchEngine:
         return results
 
     # ------------------------------------------------------------------------------------------------ one level
-    def _level(self, nodes, frontier, results, failed) -> List[int]:
-        be, L = self.be, self.L
+    def _masks_and_partition(self, nodes, frontier, given_mask: Optional[np.ndarray] = None, L: Optional[int] = None):
+        """K1 + K2 over the views of `frontier`.  given_mask: use these per-column presence masks instead of
+        computing them (IntervalPartitioner called with an explicit consensus string)."""
+        be = self.be
+        L = self.L if L is None else L
         tab, rowidx, total_cols, total_rows = self._view_table(nodes, frontier)
         n = len(frontier)
-        self.counters["cells_all"] += int((tab[:, 5] * tab[:, 7]).sum())
+        cells = float((tab[:, 5] * tab[:, 7]).sum())
         d_views, d_rowidx = be.upload(tab), be.upload(rowidx)
-        work = self._mask_work(tab)
-        d_work = be.upload(work)
-        d_mask = be.zeros(4 * total_cols)
-        be.call("mprg_column_masks", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work),
-                work.shape[0], ROWS_PER_CHUNK, be.ptr(d_mask), be.stream, work=float((tab[:, 5] * tab[:, 7]).sum()))
+        if given_mask is None:
+            work = self._mask_work(tab)
+            d_work = be.upload(work)
+            d_mask = be.zeros(4 * total_cols)
+            be.call("mprg_column_masks", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work),
+                    work.shape[0], ROWS_PER_CHUNK, be.ptr(d_mask), be.stream, work=cells)
+        else:
+            d_mask = be.upload(given_mask.astype(np.uint32))
         d_maxrun, d_stack, d_ivflag = be.zeros(4 * total_cols), be.empty(16 * total_cols), be.zeros(8 * total_cols)
         d_iv, d_niv, d_status = be.empty(12 * total_cols), be.empty(4 * n), be.empty(4 * n)
         be.call("mprg_partition", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), n, be.ptr(d_mask), L,
                 be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv), be.ptr(d_status),
-                be.stream, work=float((tab[:, 5] * tab[:, 7]).sum()))
+                be.stream, work=cells)
         self.counters["launches"] += 2
         mask = be.download(d_mask, np.uint32, total_cols)
         n_iv = be.download(d_niv, np.int32, n)
         status = be.download(d_status, np.int32, n)
         iv = be.download(d_iv, np.int32, 3 * total_cols).reshape(-1, 3)
+        return tab, d_views, d_rowidx, mask, n_iv, iv, status
+
+    def _level(self, nodes, frontier, results, failed) -> List[int]:
+        tab, d_views, d_rowidx, mask, n_iv, iv, status = self._masks_and_partition(nodes, frontier)
+        n = len(frontier)
+        total_cols = int(tab[:, 7].sum())
+        self.counters["cells_all"] += int((tab[:, 5] * tab[:, 7]).sum())
 
         # consensus codes for all columns of the level (utils/seq_utils.py:228-238), vectorised
         m = mask & ~np.uint32(BIT_N)
@@ -247,7 +264,7 @@ class BatchEngine:
                     dedupe_leaves.append(j)
                 else:
                     nd.leaf_rows = None       # single sequence == the consensus string
-            elif k > 1 or nd.parent < 0:
+            elif k > 1 or (nd.parent < 0 and self._root_forced):
                 nd.kind = "interval"
                 for a, b, _t in ivs:
                     nodes.append(NodeRec(nd.msa, ni, nd.level, nd.rows, nd.col0 + int(a), int(b) - int(a) + 1))
@@ -627,3 +644,140 @@ def tree_dump(engine: BatchEngine, res: LocusResult, ids: List[str]) -> list:
                         children=[nodes[c].node_id for c in nd.children]))
         stack.extend(reversed(nd.children))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------- single-view API
+def _one_view_engine(be, alignment: MSA, max_nesting=5, L=7) -> Tuple[BatchEngine, List[NodeRec]]:
+    eng = BatchEngine(be, max_nesting, L)
+    eng.load([alignment])
+    if 0 in eng.bad:
+        raise eng.bad[0]
+    S, C = eng.codes[0].shape
+    return eng, [NodeRec(0, -1, 0, None, 0, C)]
+
+
+def _bm_column_masks(self: BatchEngine, alignment: MSA) -> np.ndarray:
+    eng, nodes = _one_view_engine(self.be, alignment)
+    tab, rowidx, total_cols, _ = eng._view_table(nodes, [0])
+    be = eng.be
+    d_views, d_rowidx = be.upload(tab), be.upload(rowidx)
+    work = eng._mask_work(tab)
+    d_work, d_mask = be.upload(work), be.zeros(4 * total_cols)
+    be.call("mprg_column_masks", be.ptr(eng.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work), work.shape[0],
+            ROWS_PER_CHUNK, be.ptr(d_mask), be.stream)
+    return be.download(d_mask, np.uint32, total_cols)
+
+
+def _bm_partition(self: BatchEngine, alignment: MSA, L: int, consensus: Optional[str] = None):
+    """IntervalPartitioner on one alignment.  With `consensus` given, the partition follows THAT string (the
+    reference's constructor takes it as an argument); '*' columns are non-match, anything else match."""
+    if len(alignment) == 0:
+        # reference tests partition bare consensus strings with an empty alignment: no rows, no probes
+        n = len(consensus or "")
+        fake = MSA.from_strings(["A" * n]) if n else None
+        if fake is None:
+            return []
+        eng, nodes = _one_view_engine(self.be, fake, L=L)
+        eng.meta[0] = eng.meta[0][:4] + (0, eng.meta[0][5])        # zero rows
+    else:
+        eng, nodes = _one_view_engine(self.be, alignment, L=L)
+    given = None
+    if consensus is not None:
+        arr = np.frombuffer(consensus.encode(), np.uint8)
+        given = np.where(arr == ord("*"), np.uint32(0b10011), np.uint32(1))   # '*': {A, C, -}; else a single base
+    tab, _, _, mask, n_iv, iv, status = eng._masks_and_partition(nodes, [0], given_mask=given, L=L)
+    if status[0] & 2:
+        raise SequenceCurationError("All sequences in this slice contained N. Redo sequence curation.")
+    if status[0] & 1:
+        raise PartitioningError("Failed interval partitioning")
+    return [(int(a), int(b), int(t)) for a, b, t in iv[:int(n_iv[0])]]
+
+
+def _bm_row_groups(self: BatchEngine, alignment: MSA):
+    eng, nodes = _one_view_engine(self.be, alignment)
+    be = eng.be
+    tab, rowidx, total_cols, total_rows = eng._view_table(nodes, [0])
+    d_rowidx = be.upload(rowidx)
+    S = int(tab[0, 5])
+    tab[0, 10] = 0
+    d_sub = be.upload(tab)
+    d_u, d_h = be.empty(int(tab[0, 7]) * ((S + 15) // 16 * 16)), be.empty(16 * S)
+    d_ulen, d_ru, d_rg = be.empty(4 * S), be.empty(4 * S), be.empty(4 * S)
+    be.call("mprg_ungap_dedupe", be.ptr(eng.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), 1, be.ptr(d_u), be.ptr(d_h),
+            be.ptr(d_ulen), be.ptr(d_ru), be.ptr(d_rg), be.stream)
+    ru, rg = be.download(d_ru, np.int32, S), be.download(d_rg, np.int32, S)
+    ulen = be.download(d_ulen, np.int32, S)
+    ar = np.arange(S)
+    return int((ru == ar).sum()), int((rg == ar).sum()), ru, ulen
+
+
+def _bm_cluster(self: BatchEngine, alignment: MSA, kmer_size: int):
+    """kmeans_cluster_seqs (cluster_sequences.py:211-296) on one alignment → (clustered_ids, sequences|None)."""
+    eng, nodes = _one_view_engine(self.be, alignment, max_nesting=1 << 30, L=kmer_size)
+    nodes[0].level = 0
+    be, K = eng.be, kmer_size
+    tab, rowidx, total_cols, total_rows = eng._view_table(nodes, [0])
+    d_rowidx = be.upload(rowidx)
+    S = int(tab[0, 5])
+    sub = tab.copy()
+    sub[0, 10] = 0
+    d_sub = be.upload(sub)
+    d_ucodes, d_hash = be.empty(int(sub[0, 7]) * ((S + 15) // 16 * 16)), be.empty(16 * S)
+    d_ulen, d_repu, d_repg = be.empty(4 * S), be.empty(4 * S), be.empty(4 * S)
+    be.call("mprg_ungap_dedupe", be.ptr(eng.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), 1, be.ptr(d_ucodes),
+            be.ptr(d_hash), be.ptr(d_ulen), be.ptr(d_repu), be.ptr(d_repg), be.stream)
+    ul, ru = be.download(d_ulen, np.int32, S), be.download(d_repu, np.int32, S)
+    is_rep = ru == np.arange(S)
+    long_reps = np.nonzero(is_rep & (ul >= K))[0]
+    short_reps = np.nonzero(is_rep & (ul < K))[0]
+    D = len(long_reps)
+    ids = alignment.ids
+    rows = alignment.rows_as_strings()
+    rows_of_rep: Dict[int, List[int]] = {}
+    for i in range(S):
+        rows_of_rep.setdefault(int(ru[i]), []).append(i)
+
+    def ungapped(i):
+        return rows[i].replace("-", "")
+
+    def promote(clusters):
+        first_id = ids[0]
+        chosen = next((c for c in clusters if first_id in c), None)
+        if chosen is None:
+            raise ValueError(f"Could not find {first_id} in any cluster")
+        rest = [c for c in clusters if c is not chosen]
+        chosen = list(chosen)
+        chosen.remove(first_id)
+        return [[first_id] + chosen] + rest
+
+    def single():
+        everything = [ids[i] for r in long_reps for i in rows_of_rep[int(r)]] + \
+                     [ids[i] for r in short_reps for i in rows_of_rep[int(r)]]
+        first_seq = ungapped(0)
+        others = [ungapped(int(r)) for r in list(long_reps) + list(short_reps) if ungapped(int(r)) != first_seq]
+        return promote([everything]), expand_sequences([first_seq] + others)
+
+    if D <= 2:
+        return single()
+    occ = (ul[long_reps] - K + 1).astype(np.int64)
+    p = dict(q=0, ni=0, nd=nodes[0], S=S, ro=0, ru=ru, ul=ul, long_reps=long_reps, D=D,
+             occ_off=np.concatenate(([0], np.cumsum(occ))), T=int(occ.sum()))
+    eng._run_kmeans_problems(nodes, [p], sub, d_sub, d_rowidx, d_ucodes, d_ulen, S, int(sub[0, 7]))
+    k = p["num_clusters"]
+    if k == 1 or k == D:
+        return single()
+    clusters: List[List[str]] = [[] for _ in range(int(p["assign"].max()) + 1)]
+    if set(p["assign"].tolist()) != set(range(len(clusters))):
+        raise ValueError("Inconsistent cluster numbering")
+    for d, rep in enumerate(long_reps.tolist()):
+        clusters[int(p["assign"][d])].extend(ids[i] for i in rows_of_rep[rep])
+    clusters.extend([[ids[i] for i in rows_of_rep[int(r)]] for r in short_reps])
+    clusters = promote(clusters)
+    assert sum(len(c) for c in clusters) == S, "Each input sequence should be in a cluster"
+    return clusters, None
+
+
+BatchEngine.column_masks = _bm_column_masks
+BatchEngine.partition = _bm_partition
+BatchEngine.row_groups = _bm_row_groups
+BatchEngine.cluster = _bm_cluster

@@ -1,0 +1,132 @@
+"""PrgBuilder — same constructor, attributes and methods as make_prg/prg_builder.py:19-166, GPU underneath."""
+import pickle
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+from zipfile import ZipFile
+
+from .msa import load_alignment_file
+from .recursion_tree import LeafNode, NodeFactory, RecursiveTreeNode
+from .utils.prg_encoder import PrgEncoder
+
+
+class LeafNotFoundException(Exception):
+    pass
+
+
+class PrgBuilder(object):
+    def __init__(self, locus_name: str, msa_file: Path, alignment_format: str, max_nesting: int,
+                 min_match_length: int, aligner=None, _root_factory=None):
+        self._locus_name = locus_name
+        self.max_nesting = max_nesting
+        self.min_match_length = min_match_length
+        self.aligner = aligner
+        self.next_node_id = 0
+        self.site_num = 5
+        self.prg_index: Dict[Tuple[int, int], LeafNode] = {}
+        if _root_factory is not None:                      # batched CLI path: tree already built on the device
+            self.root = _root_factory(self)
+        else:
+            alignment = load_alignment_file(str(msa_file), alignment_format)
+            self.root: RecursiveTreeNode = NodeFactory.build(alignment, self, None)
+
+    @property
+    def locus_name(self):
+        return self._locus_name
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["aligner"] = None
+        return state
+
+    def __eq__(self, other) -> bool:
+        mine = (self.locus_name, self.max_nesting, self.min_match_length, self.next_node_id, self.site_num)
+        theirs = (other.locus_name, other.max_nesting, other.min_match_length, other.next_node_id, other.site_num)
+        return mine == theirs and self.prg_index == other.prg_index and self.root == other.root
+
+    def __hash__(self):
+        return hash(self.locus_name)
+
+    def replace_root(self, new_root: RecursiveTreeNode):
+        self.root = new_root
+
+    def build_prg(self) -> str:
+        self.site_num = 5
+        parts: List[str] = []
+        self.root.preorder_traversal_to_build_prg(parts)
+        return "".join(parts)
+
+    def get_next_site_num(self) -> int:
+        self.site_num += 2
+        return self.site_num - 2
+
+    def get_next_node_id(self) -> int:
+        self.next_node_id += 1
+        return self.next_node_id - 1
+
+    def update_PRG_index(self, start_index: int, end_index: int, node: LeafNode):
+        self.prg_index[(start_index, end_index)] = node
+        node.add_indexed_PRG_interval((start_index, end_index))
+
+    def clear_PRG_index(self):
+        for node in self.prg_index.values():
+            node.clear_PRG_interval_index()
+        self.prg_index.clear()
+
+    def get_node_given_interval(self, interval: Tuple[int, int]) -> LeafNode:
+        if interval not in self.prg_index:
+            raise LeafNotFoundException(
+                f"Queried PRG interval {interval} does not exist in PRG index for locus {self.locus_name}.\n"
+                f"Indexed PRG intervals: {self.prg_index.keys()}")
+        return self.prg_index[interval]
+
+    def serialize(self, filepath):
+        with open(filepath, "wb") as fh:
+            pickle.dump(self, fh, protocol=4)
+
+    @staticmethod
+    def deserialize_from_bytes(array_of_bytes: bytes) -> "PrgBuilder":
+        return pickle.loads(array_of_bytes)
+
+    @staticmethod
+    def write_prg_as_text(output_prefix: str, prg_string: str):
+        with open(output_prefix + ".prg.fa", "w") as fh:
+            fh.write(f">{Path(output_prefix).name}\n{prg_string}\n")
+
+    @staticmethod
+    def write_prg_as_binary(output_prefix: str, prg_string: str):
+        enc = PrgEncoder()
+        with open(output_prefix + ".bin", "wb") as fh:
+            enc.write(enc.encode(prg_string), fh)
+
+
+class PrgBuilderZipDatabase:
+    def __init__(self, zip_filepath: Path):
+        assert Path(zip_filepath).suffix == ".zip", "PrgBuilderZipDatabase initialised without a .zip filepath"
+        self._zip_filepath = Path(zip_filepath)
+        self._zip_file: Optional[ZipFile] = None
+
+    def save(self, locus_to_prg_builder_pickle_path: Dict[str, Path]):
+        with ZipFile(self._zip_filepath, "w") as z:
+            for name, path in locus_to_prg_builder_pickle_path.items():
+                z.write(path, name)
+
+    def load(self):
+        self._zip_file = ZipFile(self._zip_filepath)
+
+    def close(self):
+        if self._zip_file is not None:
+            self._zip_file.close()
+
+    def get_number_of_loci(self) -> int:
+        return len(self.get_loci_names())
+
+    def get_loci_names(self) -> List[str]:
+        return sorted(self._zip_file.namelist())
+
+    def get_PrgBuilder(self, locus: str) -> PrgBuilder:
+        return PrgBuilder.deserialize_from_bytes(self._zip_file.read(locus))
+
+    def __eq__(self, other) -> bool:
+        if self.get_loci_names() != other.get_loci_names():
+            return False
+        return all(self.get_PrgBuilder(l) == other.get_PrgBuilder(l) for l in self.get_loci_names())

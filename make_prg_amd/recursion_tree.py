@@ -1,0 +1,184 @@
+"""Recursion-tree node API of make_prg/recursion_tree.py over the GPU engine.
+
+NodeFactory.build(alignment, prg_builder, parent) runs the whole sub-tree on the device in level-synchronous
+passes (make_prg_amd/engine.py) and then materialises the reference's node objects: same classes, attributes,
+preorder node ids, nesting levels and traversal output (reference recursion_tree.py:27-572)."""
+from abc import ABC, abstractmethod
+from typing import List, Optional, Set, Tuple
+
+import numpy as np
+
+from .device import get_backend
+from .engine import BatchEngine, NodeRec, decode
+from .msa import MSA
+from .utils.misc import equal_msas
+from .utils.seq_utils import SequenceExpander
+
+SubMSAs = List[MSA]
+
+
+class UpdateError(Exception):
+    pass
+
+
+class RecursiveTreeNode(ABC):
+    def __init__(self, nesting_level: int, alignment: MSA, parent: Optional["RecursiveTreeNode"], prg_builder,
+                 children: Optional[List["RecursiveTreeNode"]] = None, node_id: Optional[int] = None):
+        self.nesting_level = nesting_level
+        self.alignment = alignment            # already without all-gap columns (device mask)
+        self.parent = parent
+        self.prg_builder = prg_builder
+        self._node_id = prg_builder.get_next_node_id() if node_id is None else node_id
+        self._children: List["RecursiveTreeNode"] = [] if children is None else children
+
+    @property
+    def node_id(self):
+        return self._node_id
+
+    @property
+    def children(self):
+        return self._children
+
+    def __eq__(self, other) -> bool:
+        if (self.nesting_level, self.prg_builder.locus_name, self.node_id) != \
+                (other.nesting_level, other.prg_builder.locus_name, other.node_id):
+            return False
+        if (self.parent is None) != (other.parent is None):
+            return False
+        if self.parent is not None and self.parent.node_id != other.parent.node_id:
+            return False
+        if not equal_msas(self.alignment, other.alignment):
+            return False
+        if len(self.children) != len(other.children):
+            return False
+        return all(a == b for a, b in zip(self.children, other.children))
+
+    def __hash__(self):
+        return hash((self.node_id, self.prg_builder.locus_name))
+
+    @abstractmethod
+    def preorder_traversal_to_build_prg(self, prg_as_list: List[str], delim_char: str = " "):
+        raise NotImplementedError
+
+    def is_leaf(self) -> bool:
+        return len(self.children) == 0
+
+    def is_root(self) -> bool:
+        return self.parent is None
+
+    def replace_child(self, old_child, new_child):
+        assert old_child in self.children, f"Failure to replace a child, {old_child} does not exist"
+        self.children[self.children.index(old_child)] = new_child
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}:\nId = {self.node_id}\nNesting level = {self.nesting_level}\n"
+                f"Parent = {'None' if self.parent is None else f'Id = {self.parent.node_id}'}\n"
+                f"Children = [{', '.join(f'Id = {child.node_id}' for child in self.children)}]\n"
+                f"Alignment:\n{format(self.alignment, 'fasta')}")
+
+    __str__ = __repr__
+
+
+class MultiIntervalNode(RecursiveTreeNode):
+    """Vertical partition: PRG = concatenation of the children's PRGs (reference :176-201)."""
+
+    def preorder_traversal_to_build_prg(self, prg_as_list: List[str], delim_char: str = " "):
+        for child in self.children:
+            child.preorder_traversal_to_build_prg(prg_as_list, delim_char)
+
+
+class MultiClusterNode(RecursiveTreeNode):
+    """Horizontal partition: opens a site, one allele per child (reference :204-239)."""
+
+    def preorder_traversal_to_build_prg(self, prg_as_list: List[str], delim_char: str = " "):
+        site = self.prg_builder.get_next_site_num()
+        prg_as_list.extend(f"{delim_char}{site}{delim_char}")
+        last = len(self.children) - 1
+        for i, child in enumerate(self.children):
+            child.preorder_traversal_to_build_prg(prg_as_list, delim_char)
+            prg_as_list.extend(f"{delim_char}{site + 1 if i < last else site}{delim_char}")
+
+
+class LeafNode(RecursiveTreeNode):
+    """Never partitioned; the only nodes that get indexed and updated (reference :246-391)."""
+
+    def __init__(self, nesting_level, alignment, parent, prg_builder, node_id=None):
+        super().__init__(nesting_level, alignment, parent, prg_builder, [], node_id)
+        self.new_sequences: Set[str] = set()
+        self.indexed_PRG_intervals: Set[Tuple[int, int]] = set()
+
+    def preorder_traversal_to_build_prg(self, prg_as_list: List[str], delim_char: str = " ", do_indexing=True):
+        seqs = SequenceExpander.get_expanded_sequences_from_MSA(self.alignment)
+        if len(seqs) == 1:
+            start = len(prg_as_list)
+            prg_as_list.extend(seqs[0])
+            if do_indexing:
+                self.prg_builder.update_PRG_index(start, len(prg_as_list), node=self)
+            return
+        site = self.prg_builder.get_next_site_num()
+        prg_as_list.extend(f"{delim_char}{site}{delim_char}")
+        for i, seq in enumerate(seqs):
+            start = len(prg_as_list)
+            prg_as_list.extend(seq)
+            end = len(prg_as_list)
+            prg_as_list.extend(f"{delim_char}{site + 1 if i < len(seqs) - 1 else site}{delim_char}")
+            if do_indexing:
+                self.prg_builder.update_PRG_index(start, end, node=self)
+
+    # ---- update hooks (the `update` sub-command itself is out of scope; the re-entry into the builder is kept)
+    def add_indexed_PRG_interval(self, interval: Tuple[int, int]):
+        self.indexed_PRG_intervals.add(interval)
+
+    def clear_PRG_interval_index(self):
+        self.indexed_PRG_intervals.clear()
+
+    def batch_update(self):
+        if self.new_sequences:
+            self._update_leaf()
+
+    def _update_leaf(self):
+        assert self.prg_builder.aligner is not None, "Cannot make updates without a Multiple Sequence Aligner."
+        updated = self.prg_builder.aligner.get_updated_alignment(current_alignment=self.alignment,
+                                                                 new_sequences=self.new_sequences)
+        new_node = NodeFactory.build(updated, self.prg_builder, self.parent)
+        if self.is_root():
+            self.prg_builder.replace_root(new_node)
+        else:
+            self.parent.replace_child(self, new_node)
+        self.prg_builder.clear_PRG_index()
+
+
+class NodeFactory:
+    @staticmethod
+    def build(alignment: MSA, prg_builder, parent_node: Optional[RecursiveTreeNode] = None) -> RecursiveTreeNode:
+        """reference :401-471 — leaf / multi-interval / multi-cluster decision and the whole sub-tree below it."""
+        eng = BatchEngine(get_backend(), prg_builder.max_nesting, prg_builder.min_match_length)
+        eng.load([alignment])
+        res = eng.run(root_level=0 if parent_node is None else parent_node.nesting_level,
+                      root_is_tree_root=parent_node is None)[0]
+        if res.error is not None:
+            raise res.error
+        return materialise(eng, res, alignment, prg_builder, parent_node)
+
+
+def materialise(eng: BatchEngine, res, alignment: MSA, prg_builder, parent_node=None) -> RecursiveTreeNode:
+    """Engine records → reference-style node objects; ids drawn from the builder in preorder (reference :48-55)."""
+    nodes = res.nodes
+    codes_ascii = alignment.data
+
+    def make(ni: int, parent) -> RecursiveTreeNode:
+        nd: NodeRec = nodes[ni]
+        rows = np.arange(codes_ascii.shape[0]) if nd.rows is None else nd.rows
+        block = codes_ascii[rows, nd.col0:nd.col0 + nd.ncols][:, nd.keep_cols]
+        stored = MSA(_data=block, _ids=[alignment.ids[r] for r in rows],
+                     _descs=[alignment.descriptions[r] for r in rows])
+        if nd.kind == "leaf":
+            return LeafNode(nd.level, stored, parent, prg_builder)
+        cls = MultiIntervalNode if nd.kind == "interval" else MultiClusterNode
+        node = cls(nd.level, stored, parent, prg_builder, [])
+        for c in nd.children:
+            node._children.append(make(c, node))
+        assert not node.is_leaf(), f"{cls.__name__}s should never be leaves"
+        return node
+
+    return make(res.root, parent_node)

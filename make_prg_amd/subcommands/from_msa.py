@@ -1,0 +1,171 @@
+"""`from_msa` sub-command: same flags and output files as make_prg/subcommands/from_msa.py:18-198.
+
+Instead of one worker process per alignment, the input list is sharded over the ranks of the job (one process per
+GPU; a single process when run plainly) and each rank builds its shard as ONE level-synchronous batch on its device
+(make_prg_amd/engine.py).  Per-locus policy is the reference's: a SequenceCurationError skips the locus with a
+warning, an empty alignment aborts the run (EmptyMSAError).  Rank 0 gathers the per-locus outputs and writes
+<prefix>.prg.fa (loci in sorted order), <prefix>.prg.bin(.zip), <prefix>.prg.gfa(.zip), <prefix>.update_DS.zip.
+"""
+import logging
+import os
+import pickle
+from pathlib import Path
+from typing import Dict, List
+
+import numpy as np
+
+from ..engine import BatchEngine, SequenceCurationError, build_prg
+from ..from_msa import MIN_MATCH_LEN, NESTING_LVL
+from ..msa import load_alignment_file
+from ..utils.gfa import GFA_Output
+from ..utils.io_utils import output_files_already_exist, remove_known_input_extensions, zip_bytes
+from ..utils.prg_encoder import PrgEncoder
+
+logger = logging.getLogger("make_prg_amd")
+
+
+class EmptyMSAError(Exception):
+    pass
+
+
+def register_parser(subparsers):
+    p = subparsers.add_parser("from_msa", usage="make_prg from_msa", help="Make PRG from multiple sequence alignment")
+    p.add_argument("-i", "--input", action="store", type=str, required=True,
+                   help="Multiple sequence alignment file or a directory containing such files")
+    p.add_argument("-s", "--suffix", action="store", type=str, default="",
+                   help="If the input parameter (-i, --input) is a directory, then filter for files with this suffix. "
+                        "If this parameter is not given, all files in the input directory is considered.")
+    p.add_argument("-o", "--output-prefix", dest="output_prefix", action="store", type=str, required=True,
+                   help="Prefix for the output files")
+    p.add_argument("-f", "--alignment-format", dest="alignment_format", action="store", default="fasta",
+                   help="Alignment format of MSA. Default: %(default)s")
+    p.add_argument("-N", "--max-nesting", dest="max_nesting", action="store", type=int, default=NESTING_LVL,
+                   help="Maximum number of levels to use for nesting. Default: %(default)d")
+    p.add_argument("-L", "--min-match-length", dest="min_match_length", action="store", type=int, default=MIN_MATCH_LEN,
+                   help="Minimum number of consecutive characters which must be identical for a match. Default: %(default)d")
+    p.set_defaults(func=run)
+    return p
+
+
+def get_all_input_files(input_path: str, suffix: str) -> List[Path]:
+    path = Path(input_path)
+    if not path.exists():
+        raise FileNotFoundError(f"{path} does not exist")
+    if path.is_file():
+        return [path]
+    return [p.resolve() for p in path.iterdir() if p.is_file() and p.name.endswith(suffix)]
+
+
+def _dist():
+    """(rank, world, dist module or None): a torch.distributed job if the launcher set one up."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1, None
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        backend = os.environ.get("MPRG_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size(), dist
+
+
+def shard_files(files: List[Path], rank: int, world: int) -> List[Path]:
+    """Cost-balanced shard: longest-processing-time greedy on file size (gene sizes are skewed)."""
+    order = sorted(files, key=lambda p: (-p.stat().st_size, str(p)))
+    loads = [0] * world
+    mine = []
+    for f in order:
+        r = min(range(world), key=lambda i: (loads[i], i))
+        loads[r] += f.stat().st_size
+        if r == rank:
+            mine.append(f)
+    return mine
+
+
+def build_shard(files: List[Path], options, backend=None) -> Dict[str, dict]:
+    """All loci of this rank: {locus: {prg, bin, gfa, pickle}}; loci skipped by the curation policy are absent."""
+    from ..device import get_backend
+    from ..prg_builder import PrgBuilder
+    from ..recursion_tree import materialise
+    msas, loci = [], []
+    for f in files:
+        locus = remove_known_input_extensions(f.name)
+        try:
+            msas.append(load_alignment_file(f, options.alignment_format))
+        except ValueError as err:
+            if "No records found in handle" in str(err.args[0]):
+                raise EmptyMSAError(f"No records found in MSA of locus {locus}")
+            raise
+        loci.append(locus)
+    out: Dict[str, dict] = {}
+    if not msas:
+        return out
+    eng = BatchEngine(backend or get_backend(), options.max_nesting, options.min_match_length)
+    results = eng.build(msas)
+    ot = options.output_type
+    for locus, msa, res in zip(loci, msas, results):
+        try:
+            if res.error is not None:
+                raise res.error
+            logger.info(f"Writing output files of locus {locus}")
+            prg, _, _ = build_prg(eng, res)
+            rec = dict(prg=prg)
+            if ot.prg:
+                builder = PrgBuilder(locus, None, options.alignment_format, options.max_nesting, options.min_match_length,
+                                     _root_factory=lambda b, res=res, msa=msa: materialise(eng, res, msa, b, None))
+                assert builder.build_prg() == prg
+                rec["pickle"] = pickle.dumps(builder, protocol=4)
+            if ot.binary:
+                enc = PrgEncoder()
+                rec["bin"] = np.asarray(enc.encode(prg), dtype="<u4").tobytes()
+            if ot.gfa:
+                rec["gfa"] = GFA_Output.gfa_text(prg).encode()
+            out[locus] = rec
+        except SequenceCurationError as err:
+            logger.warning(f"Skipping building PRG for {locus}. Error: {err}")
+    return out
+
+
+def write_final_files(all_loci: Dict[str, dict], output_type, output_prefix: str):
+    """reference utils/input_output_files.py:73-162."""
+    single = len(all_loci) == 1
+    if output_type.prg:
+        with open(output_prefix + ".prg.fa", "w") as fh:
+            for locus in sorted(all_loci, key=lambda l: l + ".prg.fa"):       # sorted temp-file paths in the reference
+                fh.write(f">{locus}\n{all_loci[locus]['prg']}\n")
+        zip_bytes(Path(output_prefix + ".update_DS.zip"), {l: all_loci[l]["pickle"] for l in all_loci})
+    for flag, key in ((output_type.binary, "bin"), (output_type.gfa, "gfa")):
+        if not flag:
+            continue
+        if single:
+            with open(f"{output_prefix}.prg.{key}", "wb") as fh:
+                fh.write(next(iter(all_loci.values()))[key])
+        else:
+            zip_bytes(Path(f"{output_prefix}.prg.{key}.zip"), {f"{l}.{key}": all_loci[l][key] for l in all_loci})
+
+
+def run(cl_options, backend=None):
+    options = cl_options
+    rank, world, dist = _dist()
+    input_files = get_all_input_files(options.input, options.suffix)
+    if len(input_files) == 0:
+        raise FileNotFoundError(f"No input files found in {options.input}")
+    if not options.force and output_files_already_exist(options.output_type, options.output_prefix):
+        raise RuntimeError("One or more output files already exists, aborting run...")
+    Path(options.output_prefix).parent.mkdir(parents=True, exist_ok=True)
+    mine = shard_files(input_files, rank, world) if world > 1 else input_files
+    local = build_shard(mine, options, backend)
+    if dist is not None:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(local, gathered, dst=0)          # the single exchange of the job
+        if rank != 0:
+            return
+        local = {}
+        for part in gathered:
+            local.update(part)
+    if not local:
+        logger.error("No PRGs were built, please check errors")
+        return
+    write_final_files(local, options.output_type, options.output_prefix)
