@@ -88,27 +88,21 @@ def main():
     import torch
     import torch.distributed as dist
     from make_prg_amd.backend import HipBackend
-    from make_prg_amd.engine import BatchEngine, build_prg
+    from make_prg_amd.forest import ForestEngine
 
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     be = HipBackend(local_rank)
-    eng = BatchEngine(be, max_nesting=5, min_match_length=7)
+    eng = ForestEngine(be, max_nesting=5, min_match_length=7)
     t_ing = time.perf_counter()
     eng.load(msas)                                   # ingest: encode + upload; inputs are now resident in HBM
     t_ing = time.perf_counter() - t_ing
 
     def step():
-        res = eng.run()
-        n_ok = 0
-        chars = 0
-        for r in res:
-            if r.error is None:
-                prg, _, _ = build_prg(eng, r)
-                chars += len(prg)
-                n_ok += 1
-        return n_ok, chars
+        eng.run_forest()                              # recursion forest: kernels + array-at-a-time host control
+        prgs = eng.assemble_prgs()                    # PRG strings of every locus
+        return sum(p is not None for p in prgs), sum(len(p) for p in prgs if p)
 
     def barrier():
         if world > 1:

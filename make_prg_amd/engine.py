@@ -104,6 +104,7 @@ class BatchEngine:
             arena[rm:rm + S * pitchC].reshape(S, pitchC)[:, :C] = codes
             arena[cm:cm + C * pitchS].reshape(C, pitchS)[:, :S] = codes.T
         self.meta = metas
+        self.host_arena = arena
         self.d_arena = self.be.upload(arena)
         self.counters["arena_bytes"] = int(arena.nbytes)
 

@@ -18,19 +18,37 @@ def sha(obj):
     return hashlib.sha256(obj).hexdigest()
 
 
-def run_batch(backend, texts, N, L):
+ENGINE = "forest"          # which host the parity checks drive: "forest" (array-at-a-time) or "nodes" (engine.py)
+
+
+def run_batch(backend, texts, N, L, engine=None):
     msas = [load_alignment_text(t) for t in texts]
-    eng = BatchEngine(backend, N, L)
-    res = eng.build(msas)
+    if (engine or ENGINE) == "nodes":
+        eng = BatchEngine(backend, N, L)
+        res = eng.build(msas)
+        out = []
+        for r, m in zip(res, msas):
+            if r.error is not None:
+                out.append(dict(error=type(r.error).__name__))
+                continue
+            prg, index, site = build_prg(eng, r)
+            tree = tree_dump(eng, r, m.ids)
+            out.append(dict(prg=prg, tree=tree, site_num=site, next_node_id=len(tree),
+                            prg_index=sorted([s, e, r.nodes[ni].node_id] for (s, e), ni in index.items())))
+        return out, eng
+    from make_prg_amd.forest import ForestEngine
+    eng = ForestEngine(backend, N, L)
+    eng.load(msas)
+    eng.run_forest()
+    prgs = eng.assemble_prgs(want_index=True)
     out = []
-    for r, m in zip(res, msas):
-        if r.error is not None:
-            out.append(dict(error=type(r.error).__name__))
+    for i, (p, m) in enumerate(zip(prgs, msas)):
+        if p is None:
+            out.append(dict(error=type(eng.errors[i]).__name__))
             continue
-        prg, index, site = build_prg(eng, r)
-        tree = tree_dump(eng, r, m.ids)
-        out.append(dict(prg=prg, tree=tree, site_num=site, next_node_id=len(tree),
-                        prg_index=sorted([s, e, r.nodes[ni].node_id] for (s, e), ni in index.items())))
+        tree = eng.tree_dump(i, m.ids)
+        out.append(dict(prg=p, tree=tree, site_num=5 + 2 * int(eng.site_count[i]), next_node_id=len(tree),
+                        prg_index=eng.prg_index(i)))
     return out, eng
 
 

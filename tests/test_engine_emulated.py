@@ -23,3 +23,10 @@ def test_synthetic_b(emu, golden_synthetic):
 
 def test_synthetic_c_and_deep(emu, golden_synthetic):
     assert pc.check_synthetic(emu, golden_synthetic, configs=("C", "Dsmall")) == 7
+
+
+def test_node_object_host_matches_too(emu, golden_integration, golden_synthetic, monkeypatch):
+    """engine.BatchEngine (per-node bookkeeping, used by the PrgBuilder / NodeFactory API) on the same goldens."""
+    monkeypatch.setattr(pc, "ENGINE", "nodes")
+    assert pc.check_integration(emu, golden_integration) >= 30
+    assert pc.check_synthetic(emu, golden_synthetic, configs=("B",), limit=12) == 12
