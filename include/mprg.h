@@ -120,6 +120,12 @@ int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32
                          int n_probs, int k, const int32_t *member_label, const int32_t *member_key,
                          int32_t *scratch, int32_t *out_further, void *stream);
 
+/* A16 — recursion_tree.py:266-300 (leaf alleles into the PRG string).  jobs: n_jobs x 3 int64 {arena byte offset of
+ * the first cell in the row-major copy, number of columns, destination offset in `out`}; each job writes the ASCII of
+ * its non-gap cells.  Offsets come from the host's prefix sums over the recursion tree (site markers are written by
+ * the host). */
+int mprg_emit_alleles(const uint8_t *arena, const int64_t *jobs, int64_t n_jobs, uint8_t *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

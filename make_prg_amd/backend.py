@@ -31,6 +31,7 @@ SIGNATURES = {
     "mprg_kmeans_restarts": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mprg_kmeans_select": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
     "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 5),
+    "mprg_emit_alleles": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mprg_random_sample_host": (None, [c_uint32, c_int, c_void_p]),
 }
 

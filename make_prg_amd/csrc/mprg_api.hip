@@ -12,6 +12,7 @@
 #include "k_kmer.inc"
 #include "k_kmeans.inc"
 #include "k_cluster.inc"
+#include "k_emit.inc"
 
 static thread_local char g_err[512] = "";
 static int fail(const char *what) { snprintf(g_err, sizeof g_err, "%s", what); return -1; }
@@ -130,6 +131,12 @@ int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32
   LAUNCH(k_cluster_further, n_probs, BLOCK_VIEW, stream, arena, views, rowidx, prob, k, member_label, member_key, scratch,
          out_further);
   return check_launch("k_cluster_further");
+}
+
+int mprg_emit_alleles(const uint8_t *arena, const int64_t *jobs, int64_t n_jobs, uint8_t *out, void *stream) {
+  if (n_jobs <= 0) return 0;
+  LAUNCH(k_emit_alleles, (n_jobs + 255) / 256, 256, stream, arena, jobs, (long long)n_jobs, out);
+  return check_launch("k_emit_alleles");
 }
 
 // numpy.random.RandomState(seed).random_sample(n): MT19937, init_genrand seeding, 53-bit doubles

@@ -80,6 +80,7 @@ class ForestEngine(BatchEngine):
         self.rowlists: List[np.ndarray] = []
         self.levels: List[dict] = []          # per BFS level: node index range, cons, allgap
         self.reps_pool: List[np.ndarray] = []  # leaf_mode 1: local row positions of distinct rows
+        self.reps_ulen_pool: List[np.ndarray] = []
         self.reps_n = 0
         T = Growable(dict(msa=np.int64, parent=np.int64, level=np.int64, rowlist=np.int64, col0=np.int64,
                           ncols=np.int64))
@@ -152,7 +153,7 @@ class ForestEngine(BatchEngine):
         cons = np.full(total_cols, 255, np.uint8)
         cons[single] = np.log2(mm[single]).astype(np.uint8)
         lvl = len(self.levels)
-        self.levels.append(dict(cons=cons, allgap=(mask == BIT_GAP)))
+        self.levels.append(dict(cons=cons, allgap=(mask == BIT_GAP), special=(mask & np.uint32(BITS_IUPAC | BIT_N)) != 0))
 
         # failures (per-locus policy: the locus is dropped, the batch goes on)
         if status.any():
@@ -246,6 +247,7 @@ class ForestEngine(BatchEngine):
         n_ug = _seg_sum((rep_g == local).astype(np.int64), S)
         # every selected view records its distinct rows (leaf emission, recursion_tree.py:272-274)
         self.reps_pool.append(local[is_rep])
+        self.reps_ulen_pool.append(ulen[is_rep])
         reps_off[sel] = self.reps_n + _excl_cumsum(n_uu)
         reps_cnt[sel] = n_uu
         self.reps_n += int(n_uu.sum())
@@ -448,6 +450,8 @@ class ForestEngine(BatchEngine):
         t["processed"][order] = True
         self.tab = t
         self.reps = np.concatenate(self.reps_pool) if self.reps_pool else np.zeros(0, np.int64)
+        self.reps_ulen = np.concatenate(self.reps_ulen_pool) if self.reps_ulen_pool else np.zeros(0, np.int64)
+        self.special_all = np.concatenate([lv["special"] for lv in self.levels]) if self.levels else np.zeros(0, bool)
         # the concatenated per-level column arrays (consensus codes, all-gap flags)
         offs = _excl_cumsum(np.asarray([len(lv["cons"]) for lv in self.levels], dtype=np.int64)) if self.levels else np.zeros(0, np.int64)
         self.cons_all = np.concatenate([lv["cons"] for lv in self.levels]) if self.levels else np.zeros(0, np.uint8)
@@ -478,90 +482,88 @@ def _write_markers(buf: np.ndarray, pos: np.ndarray, val: np.ndarray):
 
 
 def assemble_prgs(self: ForestEngine, want_index: bool = False):
-    """PRG string of every alignment of the batch (None for loci dropped by the curation policy), assembled
-    array-at-a-time: preorder ranks and site numbers by prefix sums over the node table, text offsets by a bottom-up
-    length pass and a top-down start pass, characters scattered into one byte buffer.
+    """PRG string of every alignment of the batch (None for loci dropped by the curation policy).
+    Host, array-at-a-time: preorder ranks and site numbers by prefix sums over the node table, text offsets by a
+    bottom-up length pass and a top-down start pass, site markers scattered with NumPy.  Device: the allele characters
+    themselves (mprg_emit_alleles copies the ungapped cells of every allele to its offset) — the PRG text is ~80 KB per
+    config-C alignment, so this is the byte-heavy part.
     reference: PrgBuilder.build_prg prg_builder.py:100-105; traversals recursion_tree.py:194-201, :222-239, :266-300."""
+    be = self.be
     t = self.tab
     n = len(t["msa"])
     M = len(self._msas)
     if n == 0:
         return [None] * M
     msa, parent, kind, nch, fch = t["msa"], t["parent"], t["kind"], t["n_child"], t["first_child"]
-    valid = ~self.failed[msa]
     meta = self.meta_arr
-    is_leaf = (kind == KIND_LEAF) & valid
-    # ---- leaf alleles ------------------------------------------------------------------------------------------
-    nseq = np.zeros(n, np.int64)
-    m0 = is_leaf & (t["leaf_mode"] == 0)
-    nseq[m0] = 1
-    m1 = np.nonzero(is_leaf & (t["leaf_mode"] == 1))[0]
-    seq_len_parts, seq_leaf_parts = [], []
-    chars = np.zeros(0, np.uint8)
-    bad_leaf_seqs: Dict[int, List[str]] = {}
-    if len(m1):
-        cnt = t["reps_cnt"][m1]
-        pair_leaf = np.repeat(m1, cnt)
-        pair_local = self.reps[np.repeat(t["reps_off"][m1], cnt) + _seg_arange(cnt)]
-        rl = t["rowlist"][pair_leaf]
-        if self.rowlists:
-            rl_len = np.asarray([len(r) for r in self.rowlists], dtype=np.int64)
-            rl_off = _excl_cumsum(rl_len)
-            rl_pool = np.concatenate(self.rowlists).astype(np.int64)
-            abs_row = np.where(rl >= 0, rl_pool[np.where(rl >= 0, rl_off[np.maximum(rl, 0)] + pair_local, 0)], pair_local)
-        else:
-            abs_row = pair_local
-        w = t["ncols"][pair_leaf]
-        pm = msa[pair_leaf]
-        base = meta[pm, 0] + abs_row * meta[pm, 2] + t["col0"][pair_leaf]
-        cell_idx = np.repeat(base, w) + _seg_arange(w)
-        codes = self.host_arena[cell_idx]
-        nongap = codes != CODE_GAP
-        plen = _seg_sum(nongap.astype(np.int64), w)
-        special = _seg_sum((codes >= 5).astype(np.int64), w) > 0          # IUPAC / N: host expansion (rare)
-        chars = _ACGT[codes[nongap]]
-        nseq_leaf = cnt.copy()
-        if special.any():
-            sp_leaves = np.unique(pair_leaf[special])
-            pair_off = _excl_cumsum(plen)
-            for lf in sp_leaves:
-                sel = np.nonzero(pair_leaf == lf)[0]
-                seqs = [chars[pair_off[i]:pair_off[i] + plen[i]].tobytes().decode() for i in sel]
+    if self.rowlists:
+        rl_len = np.asarray([len(r) for r in self.rowlists], dtype=np.int64)
+        rl_off = _excl_cumsum(rl_len)
+        rl_pool = np.concatenate(self.rowlists).astype(np.int64)
+    else:
+        rl_off, rl_pool = np.zeros(1, np.int64), np.zeros(1, np.int64)
+
+    def abs_rows(nodes_idx, local_pos):
+        rl = t["rowlist"][nodes_idx]
+        return np.where(rl >= 0, rl_pool[np.where(rl >= 0, rl_off[np.maximum(rl, 0)] + local_pos, 0)], local_pos)
+
+    leaf_all = kind == KIND_LEAF
+    # ---- alleles: (leaf, source row) pairs ----------------------------------------------------------------------------
+    l0 = np.nonzero(leaf_all & (t["leaf_mode"] == 0))[0]           # one allele = any row (all rows equal, no gaps)
+    l1 = np.nonzero(leaf_all & (t["leaf_mode"] == 1))[0]           # alleles = the distinct ungapped rows
+    cnt1 = t["reps_cnt"][l1]
+    p_leaf = np.concatenate([l0, np.repeat(l1, cnt1)])
+    rep_idx = np.repeat(t["reps_off"][l1], cnt1) + _seg_arange(cnt1)
+    p_local = np.concatenate([np.zeros(len(l0), np.int64), self.reps[rep_idx]])
+    p_len = np.concatenate([t["ncols"][l0], self.reps_ulen[rep_idx]])
+    p_row = abs_rows(p_leaf, p_local)
+    pm = msa[p_leaf]
+    p_src = meta[pm, 0] + p_row * meta[pm, 2] + t["col0"][p_leaf]
+    p_w = t["ncols"][p_leaf]
+    host_chars: Dict[int, np.ndarray] = {}                          # pair index -> ASCII (host-expanded alleles)
+    # leaves containing ambiguity codes / N: expansion on the host (utils/seq_utils.py:116-153), rare
+    if len(l1):
+        sp_cols = np.concatenate(([0], np.cumsum(self.special_all)))
+        g = t["gcol_off"][l1]
+        leaf_special = (sp_cols[g + t["ncols"][l1]] - sp_cols[g]) > 0
+        if leaf_special.any():
+            sp_set = set(l1[leaf_special].tolist())
+            keep = ~np.isin(p_leaf, l1[leaf_special])
+            extra_leaf, extra_len, extra_chars = [], [], []
+            for lf in sorted(sp_set):
+                sel = np.nonzero(p_leaf == lf)[0]
+                seqs = []
+                for i in sel:
+                    cells = self.host_arena[p_src[i]:p_src[i] + p_w[i]]
+                    seqs.append(_ACGT[cells[cells != CODE_GAP]].tobytes().decode())
                 try:
-                    bad_leaf_seqs[int(lf)] = expand_sequences(seqs)
+                    seqs = expand_sequences(seqs)
                 except SequenceCurationError as err:
                     mi = int(msa[lf])
                     self.failed[mi] = True
                     self.errors[mi] = err
-                    bad_leaf_seqs[int(lf)] = ["A"]
-            keep = ~np.isin(pair_leaf, sp_leaves)
-            # rebuild the flat arrays: regular pairs first, expanded leaves appended
-            keep_chars = np.repeat(keep, plen)
-            chars = chars[keep_chars]
-            pair_leaf, plen = pair_leaf[keep], plen[keep]
-            extra_leaf, extra_len, extra_chars = [], [], []
-            for lf, seqs in bad_leaf_seqs.items():
-                for s in seqs:
-                    extra_leaf.append(lf); extra_len.append(len(s)); extra_chars.append(np.frombuffer(s.encode(), np.uint8))
-            pair_leaf = np.concatenate([pair_leaf, np.asarray(extra_leaf, np.int64)])
-            plen = np.concatenate([plen, np.asarray(extra_len, np.int64)])
-            chars = np.concatenate([chars] + extra_chars)
-            o = np.argsort(pair_leaf, kind="stable")
-            # reorder chars accordingly
-            src_off = _excl_cumsum(plen)
-            pair_leaf, plen_sorted = pair_leaf[o], plen[o]
-            gather = np.repeat(src_off[o], plen_sorted) + _seg_arange(plen_sorted)
-            chars = chars[gather]
-            plen = plen_sorted
-            valid = ~self.failed[msa]
-            is_leaf = (kind == KIND_LEAF) & valid
-        nseq[:] = 0
-        nseq[m0 & valid] = 1
-        np.add.at(nseq, pair_leaf, 1)
-        seq_leaf, seq_len = pair_leaf, plen
-    else:
-        seq_leaf, seq_len = np.zeros(0, np.int64), np.zeros(0, np.int64)
+                    seqs = ["A"]
+                for q in seqs:
+                    extra_leaf.append(lf); extra_len.append(len(q)); extra_chars.append(np.frombuffer(q.encode(), np.uint8))
+            nkeep = int(keep.sum())
+            p_leaf = np.concatenate([p_leaf[keep], np.asarray(extra_leaf, np.int64)])
+            p_len = np.concatenate([p_len[keep], np.asarray(extra_len, np.int64)])
+            p_src = np.concatenate([p_src[keep], np.full(len(extra_leaf), -1, np.int64)])
+            p_w = np.concatenate([p_w[keep], np.zeros(len(extra_leaf), np.int64)])
+            for i, ch in enumerate(extra_chars):
+                host_chars[nkeep + i] = ch
+            o = np.argsort(p_leaf, kind="stable")
+            inv = np.empty(len(o), np.int64)
+            inv[o] = np.arange(len(o))
+            host_chars = {int(inv[i]): ch for i, ch in host_chars.items()}
+            p_leaf, p_len, p_src, p_w = p_leaf[o], p_len[o], p_src[o], p_w[o]
+        else:
+            o = np.argsort(p_leaf, kind="stable")
+            p_leaf, p_len, p_src, p_w = p_leaf[o], p_len[o], p_src[o], p_w[o]
+    valid = ~self.failed[msa]
+    nseq = np.bincount(p_leaf, minlength=n).astype(np.int64)
     nseq[~valid] = 0
+    is_leaf = leaf_all & valid
     # ---- preorder rank inside each tree ------------------------------------------------------------------------------
     size = np.ones(n, np.int64)
     for lv in reversed(self.levels):
@@ -575,8 +577,7 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False):
         if not len(idx):
             continue
         c = np.cumsum(size[idx]) - size[idx]
-        first_pos = fch[parent[idx]] - idx[0]
-        pre[idx] = pre[parent[idx]] + 1 + c - c[first_pos]
+        pre[idx] = pre[parent[idx]] + 1 + c - c[fch[parent[idx]] - idx[0]]
     # ---- site numbers: openers (cluster nodes, leaves with several alleles) in preorder -------------------------
     opener = valid & ((kind == KIND_CLUSTER) | (is_leaf & (nseq > 1)))
     order = np.lexsort((pre, msa))
@@ -590,13 +591,11 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False):
     site[order] = 5 + 2 * (cum - base_cum)
     open_len = np.where(opener, _digits(site) + 2, 0)
     mid_len = np.where(opener, _digits(site + 1) + 2, 0)
-    n_sites = np.zeros(M, np.int64)
-    np.add.at(n_sites, msa[opener], 1)
+    n_sites = np.bincount(msa[opener], minlength=M)
     # ---- text lengths bottom-up, starts top-down ---------------------------------------------------------------------
     total = np.zeros(n, np.int64)
-    total[m0 & valid] = t["ncols"][m0 & valid]
-    if len(seq_leaf):
-        np.add.at(total, seq_leaf, seq_len)
+    np.add.at(total, p_leaf, p_len)
+    total[~valid] = 0
     multi = is_leaf & (nseq > 1)
     total[multi] += open_len[multi] * 2 + (nseq[multi] - 1) * mid_len[multi]
     clus = valid & (kind == KIND_CLUSTER)
@@ -619,63 +618,55 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False):
         p = parent[idx]
         pc = kind[p] == KIND_CLUSTER
         last = idx == fch[p] + nch[p] - 1
-        sep = np.where(pc, np.where(last, open_len[p], mid_len[p]), 0)
-        x = total[idx] + sep
+        x = total[idx] + np.where(pc, np.where(last, open_len[p], mid_len[p]), 0)
         c = np.cumsum(x) - x
-        first_pos = fch[p] - idx[0]
-        start[idx] = start[p] + open_len[p] * pc + c - c[first_pos]
-    # ---- scatter the characters --------------------------------------------------------------------------------------
-    buf = np.zeros(int(msa_len.sum()), np.uint8)
-    # mode-0 leaves: the consensus slice
-    l0 = np.nonzero(m0 & valid)[0]
-    if len(l0):
-        w = t["ncols"][l0]
-        src = np.repeat(t["gcol_off"][l0], w) + _seg_arange(w)
-        dst = np.repeat(start[l0], w) + _seg_arange(w)
-        buf[dst] = _ACGT[self.cons_all[src]]
-    # cluster nodes: opening marker and the separator after each child
+        start[idx] = start[p] + open_len[p] * pc + c - c[fch[p] - idx[0]]
+    # ---- allele positions inside their leaves ----------------------------------------------------------------------------
+    npair = len(p_leaf)
+    newleaf = np.ones(npair, bool)
+    newleaf[1:] = p_leaf[1:] != p_leaf[:-1]
+    firstpair = np.nonzero(newleaf)[0]
+    k_in_leaf = np.arange(npair) - np.repeat(firstpair, np.diff(np.concatenate((firstpair, [npair]))))
+    is_multi = nseq[p_leaf] > 1
+    lastseq = k_in_leaf == nseq[p_leaf] - 1
+    x = p_len + np.where(is_multi, np.where(lastseq, open_len[p_leaf], mid_len[p_leaf]), 0)
+    c = np.cumsum(x) - x
+    spos = start[p_leaf] + np.where(is_multi, open_len[p_leaf], 0) + c - np.repeat(c[firstpair], np.diff(np.concatenate((firstpair, [npair]))))
+    okp = valid[p_leaf]
+    # ---- device: copy the allele characters ------------------------------------------------------------------------------
+    total_chars = int(msa_len.sum())
+    dev = okp & (p_src >= 0)
+    jobs = np.stack([p_src[dev], p_w[dev], spos[dev]], axis=1).astype(np.int64)
+    d_out = be.zeros(total_chars)
+    if len(jobs):
+        d_jobs = be.upload(jobs)
+        be.call("mprg_emit_alleles", be.ptr(self.d_arena), be.ptr(d_jobs), len(jobs), be.ptr(d_out), be.stream,
+                work=float(jobs[:, 1].sum() + p_len[dev].sum()))
+        self.counters["launches"] += 1
+    buf = be.download(d_out, np.uint8, total_chars).copy()
+    for i, chs in host_chars.items():
+        if okp[i]:
+            buf[spos[i]:spos[i] + len(chs)] = chs
+    # ---- host: site markers --------------------------------------------------------------------------------------------------
     cn = np.nonzero(clus)[0]
     _write_markers(buf, start[cn], site[cn])
     ch = np.nonzero(valid & (parent >= 0) & (kind[np.maximum(parent, 0)] == KIND_CLUSTER))[0]
     if len(ch):
         p = parent[ch]
-        last = ch == fch[p] + nch[p] - 1
-        _write_markers(buf, start[ch] + total[ch], np.where(last, site[p], site[p] + 1))
-    # leaves with explicit alleles
-    index = None
-    if len(seq_leaf):
-        lf = seq_leaf
-        is_multi = nseq[lf] > 1
-        k_in_leaf = _seg_arange(np.bincount(lf, minlength=n)[np.unique(lf)]) if len(lf) else np.zeros(0, np.int64)
-        lastseq = k_in_leaf == nseq[lf] - 1
-        sep = np.where(is_multi, np.where(lastseq, open_len[lf], mid_len[lf]), 0)
-        x = seq_len + sep
-        c = np.cumsum(x) - x
-        firstpair = np.nonzero(k_in_leaf == 0)[0]
-        c0 = np.repeat(c[firstpair], np.diff(np.concatenate((firstpair, [len(lf)]))))
-        spos = start[lf] + np.where(is_multi, open_len[lf], 0) + c - c0
-        ok = valid[lf]
-        dst = np.repeat(spos[ok], seq_len[ok]) + _seg_arange(seq_len[ok])
-        buf[dst] = chars[np.repeat(ok, seq_len)]
-        mo = np.nonzero(multi)[0]
-        _write_markers(buf, start[mo], site[mo])
-        mk = ok & is_multi
-        _write_markers(buf, spos[mk] + seq_len[mk], np.where(lastseq[mk], site[lf[mk]], site[lf[mk]] + 1))
-        if want_index:
-            index = (lf[ok], spos[ok] - msa_base[msa[lf[ok]]], seq_len[ok])
+        _write_markers(buf, start[ch] + total[ch], np.where(ch == fch[p] + nch[p] - 1, site[p], site[p] + 1))
+    mo = np.nonzero(multi)[0]
+    _write_markers(buf, start[mo], site[mo])
+    mk = okp & is_multi
+    _write_markers(buf, spos[mk] + p_len[mk], np.where(lastseq[mk], site[p_leaf[mk]], site[p_leaf[mk]] + 1))
     out: List[Optional[str]] = [None] * M
     whole = buf.tobytes()
     for i in np.nonzero(~self.failed)[0]:
         out[i] = whole[msa_base[i]:msa_base[i] + msa_len[i]].decode()
     self.node_id = pre
     self.site_count = n_sites
-    if want_index:
-        # prg_index: every allele of every leaf (recursion_tree.py:276-300)
-        leaves0 = l0
-        idx_leaf = np.concatenate([leaves0, index[0]]) if index is not None else leaves0
-        idx_start = np.concatenate([start[leaves0] - msa_base[msa[leaves0]], index[1]]) if index is not None else start[leaves0] - msa_base[msa[leaves0]]
-        idx_len = np.concatenate([t["ncols"][leaves0], index[2]]) if index is not None else t["ncols"][leaves0]
-        self.prg_index_arrays = (idx_leaf, idx_start, idx_start + idx_len)
+    if want_index:      # prg_index: every allele of every leaf (recursion_tree.py:276-300)
+        self.prg_index_arrays = (p_leaf[okp], spos[okp] - msa_base[msa[p_leaf[okp]]],
+                                 spos[okp] - msa_base[msa[p_leaf[okp]]] + p_len[okp])
     return out
 
 
