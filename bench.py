@@ -61,9 +61,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="alignments per GPU per step")
+    ap.add_argument("--batch", type=int, default=2048, help="alignments per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=8, help="host threads / HIP streams per GPU (each owns a sub-batch)")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes for input generation (0 = auto; use 1 under rocprofv3)")
     args = ap.parse_args()
 
@@ -93,16 +94,30 @@ def main():
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    be = HipBackend(local_rank)
-    eng = ForestEngine(be, max_nesting=5, min_match_length=7)
+    from concurrent.futures import ThreadPoolExecutor
+    n_streams = max(1, min(args.streams, args.batch))
+    bes = [HipBackend(local_rank, own_stream=n_streams > 1) for _ in range(n_streams)]
+    be = bes[0]
+    engs = [ForestEngine(b, max_nesting=5, min_match_length=7) for b in bes]
+    eng = engs[0]
+    shards = [msas[i::n_streams] for i in range(n_streams)]
     t_ing = time.perf_counter()
-    eng.load(msas)                                   # ingest: encode + upload; inputs are now resident in HBM
+    for e, b, sh in zip(engs, bes, shards):          # ingest: encode + upload; inputs are now resident in HBM
+        with b.on_stream():
+            e.load(sh)
     t_ing = time.perf_counter() - t_ing
+    pool = ThreadPoolExecutor(n_streams)
+
+    def one(i):
+        with bes[i].on_stream():
+            engs[i].run_forest()                      # recursion forest: kernels + array-at-a-time host control
+            prgs = engs[i].assemble_prgs()            # PRG strings of every locus of the sub-batch
+            bes[i].synchronize()
+        return sum(p is not None for p in prgs), sum(len(p) for p in prgs if p)
 
     def step():
-        eng.run_forest()                              # recursion forest: kernels + array-at-a-time host control
-        prgs = eng.assemble_prgs()                    # PRG strings of every locus
-        return sum(p is not None for p in prgs), sum(len(p) for p in prgs if p)
+        res = list(pool.map(one, range(n_streams)))
+        return sum(r[0] for r in res), sum(r[1] for r in res)
 
     def barrier():
         if world > 1:
@@ -111,9 +126,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    be.profile = {}
-    for key in eng.counters:
-        eng.counters[key] = 0 if key != "arena_bytes" else eng.counters[key]
+    for b in bes:
+        b.profile = {}
+    for e in engs:
+        for key in e.counters:
+            e.counters[key] = 0 if key != "arena_bytes" else e.counters[key]
     barrier()
     t0 = time.perf_counter()
     n_ok = 0
@@ -121,8 +138,14 @@ def main():
         n_ok, chars = step()
     barrier()
     dt = time.perf_counter() - t0
-    prof = be.profile_summary()
-    be.profile = None
+    prof = {}
+    for b in bes:
+        for k_, v_ in b.profile_summary().items():
+            a = prof.setdefault(k_, dict(calls=0, ms=0.0, bytes=0.0))
+            a["calls"] += v_["calls"]; a["ms"] += v_["ms"]; a["bytes"] += v_["bytes"]
+        b.profile = None
+    counters = {k_: sum(e.counters.get(k_, 0) for e in engs) for k_ in engs[0].counters}
+    counters["levels"] = max(e.counters["levels"] for e in engs)
 
     t = torch.tensor([dt], dtype=torch.float64, device=be.device)
     if world > 1:
@@ -151,13 +174,13 @@ def main():
             "vs_baseline": None, "dtype": "u8 (+f64 KMeans)", "data": "synthetic",
             "config": {"workload": "C: 30k-gene pan-genome shape (S~N(100,20) in [20,300] rows x 1000-3000 cols, "
                                    "SURVEY.md §8d generator), -N 5 -L 7; one step = one resident batch per GPU",
-                       "batch_per_gpu": args.batch, "parallelism": f"shard{world}",
+                       "batch_per_gpu": args.batch, "parallelism": f"shard{world}", "host_threads_streams_per_gpu": n_streams,
                        "step_includes": "recursion forest on device + host control + PRG string emission",
                        "ingest_s_excluded": round(t_ing, 3), "device_ms_per_step": round(dev_ms / args.steps, 3),
-                       "levels": eng.counters["levels"] / args.steps, "launches_per_step": eng.counters["launches"] / args.steps,
-                       "kmeans_fits_per_step": eng.counters["fits"] / args.steps,
-                       "B_alg_bytes_per_step": (eng.counters["cells_all"] + eng.counters["cells_clustered"]
-                                                + eng.counters["kmeans_bytes"]) / args.steps,
+                       "levels": counters["levels"] / args.steps, "launches_per_step": counters["launches"] / args.steps,
+                       "kmeans_fits_per_step": counters["fits"] / args.steps,
+                       "B_alg_bytes_per_step": (counters["cells_all"] + counters["cells_clustered"]
+                                                + counters["kmeans_bytes"]) / args.steps,
                        "kernels": kernels},
             "roofline": roof,
             "cpu_baseline": cpu,

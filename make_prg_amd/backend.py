@@ -86,7 +86,7 @@ class _Base:
 class HipBackend(_Base):
     name = "hip"
 
-    def __init__(self, device: Optional[int] = None, lib_path: str = HIP_LIB_PATH):
+    def __init__(self, device: Optional[int] = None, lib_path: str = HIP_LIB_PATH, own_stream: bool = False):
         import torch
         if not os.path.exists(lib_path):
             raise MprgError(f"{lib_path} not found: build it with `python __graft_entry__.py build` (hipcc, gfx950)")
@@ -98,8 +98,14 @@ class HipBackend(_Base):
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self.lib = bind(ctypes.CDLL(lib_path))
-        self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        # own_stream: a private HIP stream, so that several host threads (each with its own backend + engine) overlap
+        # their kernels, copies and host work; use `with backend.on_stream():` around the work of that thread
+        self.stream_obj = torch.cuda.Stream(self.device) if own_stream else torch.cuda.current_stream(self.device)
+        self.stream = self.stream_obj.cuda_stream
         self.n_cus = self.lib.mprg_device_cus()
+
+    def on_stream(self):
+        return self.torch.cuda.stream(self.stream_obj)
 
     # buffers are flat uint8 tensors; sizes in bytes
     def empty(self, nbytes: int):
@@ -125,7 +131,7 @@ class HipBackend(_Base):
         return buf.data_ptr()
 
     def synchronize(self):
-        self.torch.cuda.synchronize(self.device)
+        self.stream_obj.synchronize()
 
     def _event_pair(self):
         # torch.cuda.Event wraps hipEvent_t; kernels are enqueued on torch's current stream, the one these record on

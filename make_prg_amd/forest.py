@@ -77,7 +77,9 @@ class ForestEngine(BatchEngine):
         self.errors: Dict[int, Exception] = dict(self.bad)
         for i in self.bad:
             self.failed[i] = True
-        self.rowlists: List[np.ndarray] = []
+        self.rl_pool = np.zeros(0, np.int64)      # all row lists of cluster children, concatenated
+        self.rl_off = np.zeros(0, np.int64)
+        self.rl_len = np.zeros(0, np.int64)
         self.levels: List[dict] = []          # per BFS level: node index range, cons, allgap
         self.reps_pool: List[np.ndarray] = []  # leaf_mode 1: local row positions of distinct rows
         self.reps_ulen_pool: List[np.ndarray] = []
@@ -112,12 +114,9 @@ class ForestEngine(BatchEngine):
         nrows = meta[m, 4].copy()
         rows_off = np.full(n, -1, np.int64)
         if has.any():
-            uniq, inv = np.unique(rl[has], return_inverse=True)
-            lens = np.asarray([len(self.rowlists[u]) for u in uniq], dtype=np.int64)
-            offs = _excl_cumsum(lens)
-            rows_off[has] = offs[inv]
-            nrows[has] = lens[inv]
-            rowidx = np.concatenate([self.rowlists[u] for u in uniq]).astype(np.int32)
+            rows_off[has] = self.rl_off[rl[has]]          # offsets into the global pool (uploaded whole)
+            nrows[has] = self.rl_len[rl[has]]
+            rowidx = self.rl_pool.astype(np.int32)
         else:
             rowidx = np.zeros(1, np.int32)
         tab[:, 4], tab[:, 5], tab[:, 6], tab[:, 7] = rows_off, nrows, cur["col0"], cur["ncols"]
@@ -400,15 +399,14 @@ class ForestEngine(BatchEngine):
         # MSA row indices of the children (views with a row list map local positions through it)
         vj = sel[pq[p_o]]                                          # frontier position of each sorted row's view
         rl = cur["rowlist"][vj]
-        rows_abs = l_o.copy()
-        if (rl >= 0).any():
-            for r in np.unique(rl[rl >= 0]):
-                mk = rl == r
-                rows_abs[mk] = self.rowlists[r][l_o[mk]]
-        base = len(self.rowlists)
-        bounds = np.concatenate((gstart, [len(order)]))
-        for g in range(len(gstart)):
-            self.rowlists.append(rows_abs[bounds[g]:bounds[g + 1]].astype(np.int32))
+        if len(self.rl_pool):
+            rows_abs = np.where(rl >= 0, self.rl_pool[np.where(rl >= 0, self.rl_off[np.maximum(rl, 0)] + l_o, 0)], l_o)
+        else:
+            rows_abs = l_o
+        base = len(self.rl_len)
+        self.rl_off = np.concatenate([self.rl_off, len(self.rl_pool) + gstart])
+        self.rl_len = np.concatenate([self.rl_len, glen])
+        self.rl_pool = np.concatenate([self.rl_pool, rows_abs])
         par_j = sel[pq[gprob]]                                     # frontier position of the parent of every child
         kind[sel[pq[splits]]] = KIND_CLUSTER
         node_level[sel[pq[splits]]] += 1                           # recursion_tree.py:459
@@ -496,12 +494,8 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False):
         return [None] * M
     msa, parent, kind, nch, fch = t["msa"], t["parent"], t["kind"], t["n_child"], t["first_child"]
     meta = self.meta_arr
-    if self.rowlists:
-        rl_len = np.asarray([len(r) for r in self.rowlists], dtype=np.int64)
-        rl_off = _excl_cumsum(rl_len)
-        rl_pool = np.concatenate(self.rowlists).astype(np.int64)
-    else:
-        rl_off, rl_pool = np.zeros(1, np.int64), np.zeros(1, np.int64)
+    rl_off = self.rl_off if len(self.rl_off) else np.zeros(1, np.int64)
+    rl_pool = self.rl_pool if len(self.rl_pool) else np.zeros(1, np.int64)
 
     def abs_rows(nodes_idx, local_pos):
         rl = t["rowlist"][nodes_idx]
@@ -683,7 +677,7 @@ def forest_tree_dump(self: ForestEngine, mi: int, ids: List[str]) -> list:
     while stack:
         ni = stack.pop()
         rl = int(t["rowlist"][ni])
-        rows = np.arange(codes.shape[0]) if rl < 0 else self.rowlists[rl]
+        rows = np.arange(codes.shape[0]) if rl < 0 else self.rl_pool[self.rl_off[rl]:self.rl_off[rl] + self.rl_len[rl]]
         c0, w, g = int(t["col0"][ni]), int(t["ncols"][ni]), int(t["gcol_off"][ni])
         keep = ~self.allgap_all[g:g + w]
         block = decode(codes[rows, c0:c0 + w][:, keep])
