@@ -67,11 +67,18 @@ int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *ro
  * utils/seq_utils.py:58-70 (unique gapped / ungapped counts).  One workgroup per view.
  * views[AUX0] = byte offset of this view's region in `ucodes` (n_cols * n_rows_pad bytes, n_rows_pad =
  * round_up(n_rows,16)); ungapped codes are stored transposed: character j of row position i at j*n_rows_pad + i.
- * out (per row, at row_off): ulen int32, rep_u int32 (smallest row position with identical ungapped content),
- * rep_g int32 (same for gapped content).  scratch: hashes uint64[2*total_rows]. */
-int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
+ * per row (at row_off): ulen, rep_u (smallest row position with identical ungapped content), rep_g (same for gapped
+ * content), d_of_row (index of the row's sequence among the distinct sequences of length >= kmer_size, first-appearance
+ * order; -1 if shorter), s_of_row (index among the distinct shorter sequences; -1 if long).
+ * per view, compact lists (at row_off): reps_pos / reps_len = row positions and ungapped lengths of the distinct rows;
+ * seqrow = row positions of the distinct long sequences; occ_off (at row_off + view index, D+1 entries) = exclusive
+ * prefix sums of their k-mer occurrence counts.
+ * summary int64[8*n_views] = {distinct ungapped, distinct gapped, D (distinct long), T (k-mer occurrences),
+ * total ungapped length of the distinct rows, distinct short, 0, 0}.  scratch: hashes uint64[2*total_rows]. */
+int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views, int kmer_size,
                       uint8_t *ucodes, uint64_t *hashes, int32_t *ulen, int32_t *rep_u, int32_t *rep_g,
-                      void *stream);
+                      int32_t *d_of_row, int32_t *s_of_row, int32_t *reps_pos, int32_t *reps_len, int32_t *seqrow,
+                      int64_t *occ_off, int64_t *summary, void *stream);
 
 /* A9b — from_msa/cluster_sequences.py:26-38 (count_distinct_kmers): k-mer dictionary in first-appearance order.
  * One workgroup per clustering problem.  prob: n_probs x MPRG_PROB_FIELDS int64 (see enum).  seqrow int32[]:
@@ -112,16 +119,32 @@ int mprg_kmeans_select(const int64_t *prob, int n_probs, int k, int n_init, cons
 void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
 
 /* A10 — cluster_sequences.py:59-111 (majority string, Hamming distance, one-reference-like test, cluster_further).
- * One workgroup per problem.  member_label int32 per row position of the view at row_off (-1 = row takes no part),
- * member_key int32 per row (order in which the reference enumerates the cluster's rows; ties in the per-column
- * majority go to the symbol seen first in that order).  out_further[n_probs] = 1 if some cluster is not
- * one-reference-like. */
+ * One workgroup per problem.  A row takes part if d_of_row >= 0; its cluster is labels[prob[LABEL_OFF] + d_of_row]
+ * (labels == NULL: a single cluster).  Ties in the per-column majority go to the symbol seen first in the order in
+ * which the reference enumerates the cluster's rows (distinct sequence, then row).  If `assign` is given the labels
+ * of these problems are also copied there (the fit is the accepted one).  out_further[n_probs] = 1 if some cluster is
+ * not one-reference-like. */
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
-                         int n_probs, int k, const int32_t *member_label, const int32_t *member_key,
+                         int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                          int32_t *scratch, int32_t *out_further, void *stream);
 
-/* A16 — recursion_tree.py:266-300 (leaf alleles into the PRG string).  jobs: n_jobs x 3 int64 {arena byte offset of
- * the first cell in the row-major copy, number of columns, destination offset in `out`}; each job writes the ASCII of
+/* A12/A14 — cluster_sequences.py:287-296 + recursion_tree.py:558-572: row lists of the children of MultiClusterNodes.
+ * split_info: n_probs x 3 int64 {number of KMeans clusters, offset of the problem's n_rows entries in pool_out,
+ * offset of its child sizes in child_sizes}.  Children order: the cluster holding the first row, then the KMeans
+ * clusters by label, then one cluster per distinct short sequence in first-appearance order; rows keep MSA order. */
+int mprg_split_children(const int64_t *views, const int32_t *rowidx, const int64_t *prob, int n_probs,
+                        const int64_t *split_info, const int32_t *d_of_row, const int32_t *s_of_row,
+                        const int32_t *assign, int32_t *pool_out, int32_t *child_sizes, void *stream);
+
+/* A16 (per leaf) — recursion_tree.py:266-300: expands leaves into allele copy jobs and writes the leaf's own site
+ * markers.  leaves: n x 10 int64 {MSA row-major base, pitchC, rows_off (-1 identity), col0, ncols, reps_off into
+ * reps_pos/reps_len (-1: one allele = the first row, length ncols), alleles, destination of the leaf text, site number
+ * (0: single allele, no markers), first job index}.  jobs: 4 int64 per allele {source, columns, destination, length}. */
+int mprg_leaf_jobs(const int64_t *leaves, int64_t n_leaves, const int32_t *rowidx, const int32_t *reps_pos,
+                   const int32_t *reps_len, int64_t *jobs, uint8_t *out, void *stream);
+
+/* A16 — recursion_tree.py:266-300 (leaf alleles into the PRG string).  jobs: n_jobs x 4 int64 {arena byte offset of
+ * the first cell in the row-major copy, number of columns, destination offset in `out`, allele length}; each job writes the ASCII of
  * its non-gap cells.  Offsets come from the host's prefix sums over the recursion tree (site markers are written by
  * the host). */
 int mprg_emit_alleles(const uint8_t *arena, const int64_t *jobs, int64_t n_jobs, uint8_t *out, void *stream);

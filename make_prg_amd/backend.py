@@ -23,14 +23,16 @@ SIGNATURES = {
     "mprg_device_cus": (c_int, []),
     "mprg_column_masks": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p, c_void_p]),
     "mprg_partition": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int] + [c_void_p] * 7),
-    "mprg_ungap_dedupe": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 6),
+    "mprg_ungap_dedupe": (c_int, [c_void_p] * 3 + [c_int, c_int] + [c_void_p] * 13),
     "mprg_kmer_dictionary": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8),
     "mprg_kmer_counts": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7),
     "mprg_kmeans_workspace_doubles": (c_int64, [c_int64, c_int64, c_int, c_int]),
     "mprg_kmeans_prepare": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mprg_kmeans_restarts": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mprg_kmeans_select": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
-    "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 5),
+    "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 6),
+    "mprg_split_children": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 7),
+    "mprg_leaf_jobs": (c_int, [c_void_p, c_int64] + [c_void_p] * 6),
     "mprg_emit_alleles": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mprg_random_sample_host": (None, [c_uint32, c_int, c_void_p]),
 }
@@ -129,6 +131,13 @@ class HipBackend(_Base):
 
     def ptr(self, buf) -> int:
         return buf.data_ptr()
+
+    def grown(self, buf, used_bytes: int, new_bytes: int):
+        """A larger buffer holding the first used_bytes of buf (device-to-device copy)."""
+        new = self.torch.empty(int(new_bytes), dtype=self.torch.uint8, device=self.device)
+        if used_bytes:
+            new[:used_bytes].copy_(buf[:used_bytes])
+        return new
 
     def synchronize(self):
         self.stream_obj.synchronize()

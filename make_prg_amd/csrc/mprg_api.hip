@@ -28,6 +28,12 @@ static int check_launch(const char *name) {
 #endif
 
 #define BLOCK_VIEW 256
+#include <stdlib.h>
+static int env_threads(const char *name, int dflt) {
+  const char *e = getenv(name);
+  const int v = e ? atoi(e) : dflt;
+  return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : dflt;
+}
 
 extern "C" {
 
@@ -67,11 +73,13 @@ int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *ro
   return check_launch("k_partition");
 }
 
-int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
+int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views, int kmer_size,
                       uint8_t *ucodes, uint64_t *hashes, int32_t *ulen, int32_t *rep_u, int32_t *rep_g,
-                      void *stream) {
+                      int32_t *d_of_row, int32_t *s_of_row, int32_t *reps_pos, int32_t *reps_len, int32_t *seqrow,
+                      int64_t *occ_off, int64_t *summary, void *stream) {
   if (n_views <= 0) return 0;
-  LAUNCH(k_ungap_dedupe, n_views, BLOCK_VIEW, stream, arena, views, rowidx, ucodes, hashes, ulen, rep_u, rep_g);
+  LAUNCH(k_ungap_dedupe, n_views, BLOCK_VIEW, stream, arena, views, rowidx, kmer_size, ucodes, hashes, ulen, rep_u, rep_g,
+         d_of_row, s_of_row, reps_pos, reps_len, seqrow, occ_off, summary);
   return check_launch("k_ungap_dedupe");
 }
 
@@ -112,7 +120,7 @@ int mprg_kmeans_restarts(const int64_t *prob, int n_probs, int k, int n_init, co
   if (n_probs <= 0) return 0;
   if (k < 2 || k > KM_KMAX) return fail("k must be in 2..10");
   const int n_trials = 2 + (int)log((double)k);
-  LAUNCH(k_kmeans_restart, n_probs * n_init, 256, stream, prob, k, n_init, n_trials, uniforms_dev, ws, km_status);
+  LAUNCH(k_kmeans_restart, n_probs * n_init, env_threads("MPRG_KM_THREADS", 256), stream, prob, k, n_init, n_trials, uniforms_dev, ws, km_status);
   return check_launch("k_kmeans_restart");
 }
 
@@ -125,12 +133,28 @@ int mprg_kmeans_select(const int64_t *prob, int n_probs, int k, int n_init, cons
 }
 
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
-                         int n_probs, int k, const int32_t *member_label, const int32_t *member_key,
+                         int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                          int32_t *scratch, int32_t *out_further, void *stream) {
   if (n_probs <= 0) return 0;
-  LAUNCH(k_cluster_further, n_probs, BLOCK_VIEW, stream, arena, views, rowidx, prob, k, member_label, member_key, scratch,
+  LAUNCH(k_cluster_further, n_probs, BLOCK_VIEW, stream, arena, views, rowidx, prob, k, d_of_row, labels, assign, scratch,
          out_further);
   return check_launch("k_cluster_further");
+}
+
+int mprg_split_children(const int64_t *views, const int32_t *rowidx, const int64_t *prob, int n_probs,
+                        const int64_t *split_info, const int32_t *d_of_row, const int32_t *s_of_row,
+                        const int32_t *assign, int32_t *pool_out, int32_t *child_sizes, void *stream) {
+  if (n_probs <= 0) return 0;
+  LAUNCH(k_split_children, n_probs, 64, stream, views, rowidx, prob, split_info, d_of_row, s_of_row, assign, pool_out,
+         child_sizes);
+  return check_launch("k_split_children");
+}
+
+int mprg_leaf_jobs(const int64_t *leaves, int64_t n_leaves, const int32_t *rowidx, const int32_t *reps_pos,
+                   const int32_t *reps_len, int64_t *jobs, uint8_t *out, void *stream) {
+  if (n_leaves <= 0) return 0;
+  LAUNCH(k_leaf_jobs, (n_leaves + 255) / 256, 256, stream, leaves, (long long)n_leaves, rowidx, reps_pos, reps_len, jobs, out);
+  return check_launch("k_leaf_jobs");
 }
 
 int mprg_emit_alleles(const uint8_t *arena, const int64_t *jobs, int64_t n_jobs, uint8_t *out, void *stream) {

@@ -278,6 +278,22 @@ class BatchEngine:
                                                      dedupe_leaves, results, failed))
         return next_frontier
 
+
+    def _dedupe(self, d_sub, d_rowidx, n_views: int, tot_rows: int, tot_u: int, work: float = 0.0):
+        """mprg_ungap_dedupe over the views of `d_sub`; returns the device buffers by name."""
+        be = self.be
+        R = max(tot_rows, 1)
+        b = dict(ucodes=be.empty(tot_u), hash=be.empty(16 * R), ulen=be.empty(4 * R), rep_u=be.empty(4 * R),
+                 rep_g=be.empty(4 * R), d_of_row=be.empty(4 * R), s_of_row=be.empty(4 * R), reps_pos=be.empty(4 * R),
+                 reps_len=be.empty(4 * R), seqrow=be.empty(4 * R), occ_off=be.empty(8 * (R + n_views)),
+                 summary=be.empty(64 * max(n_views, 1)))
+        be.call("mprg_ungap_dedupe", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), n_views, self.L,
+                be.ptr(b["ucodes"]), be.ptr(b["hash"]), be.ptr(b["ulen"]), be.ptr(b["rep_u"]), be.ptr(b["rep_g"]),
+                be.ptr(b["d_of_row"]), be.ptr(b["s_of_row"]), be.ptr(b["reps_pos"]), be.ptr(b["reps_len"]),
+                be.ptr(b["seqrow"]), be.ptr(b["occ_off"]), be.ptr(b["summary"]), be.stream, work=work)
+        self.counters["launches"] += 1
+        return b
+
     # ------------------------------------------------------------------------------------------------ clustering
     def _cluster_stage(self, nodes, frontier, tab, d_views, d_rowidx, cands, leaves, results, failed) -> List[int]:
         """A9-A14 for every single-non-match-interval view of the level (+ row grouping for non-trivial leaves)."""
@@ -292,15 +308,11 @@ class BatchEngine:
         sub[:, 8] = np.cumsum(sub[:, 7]) - sub[:, 7]
         tot_rows, tot_u, tot_cols = int(sub[:, 5].sum()), int(usize.sum()), int(sub[:, 7].sum())
         d_sub = be.upload(sub)
-        d_ucodes, d_hash = be.empty(tot_u), be.empty(16 * tot_rows)
-        d_ulen, d_repu, d_repg = be.empty(4 * tot_rows), be.empty(4 * tot_rows), be.empty(4 * tot_rows)
-        be.call("mprg_ungap_dedupe", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), len(sel), be.ptr(d_ucodes),
-                be.ptr(d_hash), be.ptr(d_ulen), be.ptr(d_repu), be.ptr(d_repg), be.stream,
-                work=2.0 * float((sub[:, 5] * sub[:, 7]).sum()))
-        self.counters["launches"] += 1
-        ulen = be.download(d_ulen, np.int32, tot_rows)
-        rep_u = be.download(d_repu, np.int32, tot_rows)
-        rep_g = be.download(d_repg, np.int32, tot_rows)
+        dd = self._dedupe(d_sub, d_rowidx, len(sel), tot_rows, tot_u, work=2.0 * float((sub[:, 5] * sub[:, 7]).sum()))
+        d_ucodes, d_ulen = dd["ucodes"], dd["ulen"]
+        ulen = be.download(dd["ulen"], np.int32, tot_rows)
+        rep_u = be.download(dd["rep_u"], np.int32, tot_rows)
+        rep_g = be.download(dd["rep_g"], np.int32, tot_rows)
 
         new_nodes: List[int] = []
         for q in range(len(cands), len(sel)):           # leaves: distinct ungapped rows in first-appearance order
@@ -334,7 +346,7 @@ class BatchEngine:
             probs.append(dict(q=q, ni=ni, nd=nd, S=S, ro=ro, ru=ru, ul=ul, long_reps=long_reps, D=D,
                               occ_off=np.concatenate(([0], np.cumsum(occ))), T=int(occ.sum())))
         if probs:
-            self._run_kmeans_problems(nodes, probs, sub, d_sub, d_rowidx, d_ucodes, d_ulen, tot_rows, tot_cols)
+            self._run_kmeans_problems(nodes, probs, sub, d_sub, d_rowidx, d_ucodes, d_ulen, tot_rows, tot_cols, dd["d_of_row"])
             for p in probs:
                 new_nodes.extend(self._finish_cluster_node(nodes, p))
         return new_nodes
@@ -346,7 +358,7 @@ class BatchEngine:
             self._uniform_cache[k] = self.be.upload(u)
         return self._uniform_cache[k]
 
-    def _run_kmeans_problems(self, nodes, probs, sub, d_sub, d_rowidx, d_ucodes, d_ulen, tot_rows, tot_cols):
+    def _run_kmeans_problems(self, nodes, probs, sub, d_sub, d_rowidx, d_ucodes, d_ulen, tot_rows, tot_cols, d_dor):
         be, K = self.be, self.L
         P = len(probs)
         ptab = np.zeros((P, PF), np.int64)
@@ -385,33 +397,18 @@ class BatchEngine:
         be.call("mprg_kmeans_prepare", be.ptr(d_ptab), P, be.ptr(d_x), be.ptr(d_ws), be.stream)
         self.counters["launches"] += 3
 
-        # member labels / keys per row of the sub-table (cluster_sequences.py:252-274 loop state)
-        mlabel = np.full(tot_rows, -1, np.int32)
-        mkey = np.zeros(tot_rows, np.int32)
         for p in probs:
-            S, ro, ru, ul = p["S"], p["ro"], p["ru"], p["ul"]
-            d_of_rep = np.full(S, -1, np.int64)
-            d_of_rep[p["long_reps"]] = np.arange(p["D"])
-            p["d_of_row"] = d_of_rep[ru]                     # distinct-sequence index of every row (-1: short)
-            member = p["d_of_row"] >= 0
-            order = np.lexsort((np.arange(S), p["d_of_row"]))
-            key = np.empty(S, np.int64)
-            key[order] = np.arange(S)
-            mkey[ro:ro + S] = key
             p["assign"] = np.zeros(p["D"], np.int64)
             p["num_clusters"] = 1
-            p["active"] = True
-            mlabel[ro:ro + S] = np.where(member, 0, -1)
-        d_mkey = be.upload(mkey)
         d_scratch, d_further = be.empty(12 * tot_cols + 64), be.empty(4 * P)
 
         def check(active_idx, k):
-            """cluster_further() for the listed problems with their current assignment (k clusters)."""
-            sub_ptab = ptab[active_idx]
-            d_sp = be.upload(sub_ptab)
-            d_ml = be.upload(mlabel)
+            """cluster_further() for the listed problems with their current assignment (k clusters): the kernel reads
+            the labels the KMeans select step just wrote (k = 1: a single cluster)."""
+            d_sp = be.upload(ptab[active_idx])
             be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp),
-                    len(active_idx), k, be.ptr(d_ml), be.ptr(d_mkey), be.ptr(d_scratch), be.ptr(d_further), be.stream)
+                    len(active_idx), k, be.ptr(d_dor), be.ptr(d_labels) if k > 1 else None, None, be.ptr(d_scratch),
+                    be.ptr(d_further), be.stream)
             self.counters["launches"] += 1
             return be.download(d_further, np.int32, len(active_idx))
 
@@ -460,9 +457,6 @@ class BatchEngine:
                     p["num_clusters"] -= 1
                     continue
                 p["assign"] = lab
-                ro, S = p["ro"], p["S"]
-                member = p["d_of_row"] >= 0
-                mlabel[ro:ro + S] = np.where(member, lab[np.maximum(p["d_of_row"], 0)], -1)
                 nxt.append(i)
             if be.profile is not None and be.profile.get("mprg_kmeans_restarts"):
                 a0, a1, _ = be.profile["mprg_kmeans_restarts"][-1]       # algorithmic bytes known only after the fit
@@ -702,12 +696,9 @@ def _bm_row_groups(self: BatchEngine, alignment: MSA):
     S = int(tab[0, 5])
     tab[0, 10] = 0
     d_sub = be.upload(tab)
-    d_u, d_h = be.empty(int(tab[0, 7]) * ((S + 15) // 16 * 16)), be.empty(16 * S)
-    d_ulen, d_ru, d_rg = be.empty(4 * S), be.empty(4 * S), be.empty(4 * S)
-    be.call("mprg_ungap_dedupe", be.ptr(eng.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), 1, be.ptr(d_u), be.ptr(d_h),
-            be.ptr(d_ulen), be.ptr(d_ru), be.ptr(d_rg), be.stream)
-    ru, rg = be.download(d_ru, np.int32, S), be.download(d_rg, np.int32, S)
-    ulen = be.download(d_ulen, np.int32, S)
+    dd = eng._dedupe(d_sub, d_rowidx, 1, S, int(tab[0, 7]) * ((S + 15) // 16 * 16))
+    ru, rg = be.download(dd["rep_u"], np.int32, S), be.download(dd["rep_g"], np.int32, S)
+    ulen = be.download(dd["ulen"], np.int32, S)
     ar = np.arange(S)
     return int((ru == ar).sum()), int((rg == ar).sum()), ru, ulen
 
@@ -723,11 +714,9 @@ def _bm_cluster(self: BatchEngine, alignment: MSA, kmer_size: int):
     sub = tab.copy()
     sub[0, 10] = 0
     d_sub = be.upload(sub)
-    d_ucodes, d_hash = be.empty(int(sub[0, 7]) * ((S + 15) // 16 * 16)), be.empty(16 * S)
-    d_ulen, d_repu, d_repg = be.empty(4 * S), be.empty(4 * S), be.empty(4 * S)
-    be.call("mprg_ungap_dedupe", be.ptr(eng.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), 1, be.ptr(d_ucodes),
-            be.ptr(d_hash), be.ptr(d_ulen), be.ptr(d_repu), be.ptr(d_repg), be.stream)
-    ul, ru = be.download(d_ulen, np.int32, S), be.download(d_repu, np.int32, S)
+    dd = eng._dedupe(d_sub, d_rowidx, 1, S, int(sub[0, 7]) * ((S + 15) // 16 * 16))
+    d_ucodes, d_ulen = dd["ucodes"], dd["ulen"]
+    ul, ru = be.download(dd["ulen"], np.int32, S), be.download(dd["rep_u"], np.int32, S)
     is_rep = ru == np.arange(S)
     long_reps = np.nonzero(is_rep & (ul >= K))[0]
     short_reps = np.nonzero(is_rep & (ul < K))[0]
@@ -763,7 +752,7 @@ def _bm_cluster(self: BatchEngine, alignment: MSA, kmer_size: int):
     occ = (ul[long_reps] - K + 1).astype(np.int64)
     p = dict(q=0, ni=0, nd=nodes[0], S=S, ro=0, ru=ru, ul=ul, long_reps=long_reps, D=D,
              occ_off=np.concatenate(([0], np.cumsum(occ))), T=int(occ.sum()))
-    eng._run_kmeans_problems(nodes, [p], sub, d_sub, d_rowidx, d_ucodes, d_ulen, S, int(sub[0, 7]))
+    eng._run_kmeans_problems(nodes, [p], sub, d_sub, d_rowidx, d_ucodes, d_ulen, S, int(sub[0, 7]), dd["d_of_row"])
     k = p["num_clusters"]
     if k == 1 or k == D:
         return single()

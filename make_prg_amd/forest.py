@@ -1,14 +1,14 @@
 """Array-at-a-time host for the batched from_msa build (the throughput path of bench.py and the CLI).
 
-Same device calls and the same decisions as make_prg_amd/engine.py (which keeps the node-object bookkeeping used by
-the per-alignment API), but every host step works on whole NumPy arrays over ALL node views of a recursion level:
-node table as a struct of arrays, vectorised leaf / multi-interval / cluster classification, segment operations for
-the row groups of the clustering stage, and PRG text assembled by prefix sums into one byte buffer.  The Python host
-still drives the recursion (north star); it just never loops over nodes.
+Division of labour: everything that is per ROW or per CELL of an alignment stays on the device (row groups, k-mers,
+KMeans, majority/Hamming, children row lists, PRG characters); the Python host only touches per-NODE arrays — a
+struct-of-arrays node table that grows one recursion level at a time, vectorised leaf / multi-interval / cluster
+classification, per-problem KMeans loop control, and the prefix sums that place every node's text in the PRG string.
+The Python host still drives the recursion (north star); it never loops over nodes, rows or characters.
 
 Reference semantics: recursion_tree.py:401-471 (NodeFactory.build), cluster_sequences.py:211-296,
 prg_builder.py:100-119 + recursion_tree.py:194-300 (traversals).  Row ids are assumed unique inside an alignment
-(the reference partitions cluster children by id); alignments with duplicate ids are routed to engine.BatchEngine.
+(the reference partitions cluster children by id); the per-alignment API (engine.BatchEngine) keeps id semantics.
 """
 from typing import Dict, List, Optional
 
@@ -17,7 +17,7 @@ import numpy as np
 from .backend import MprgError
 from .engine import (BIT_GAP, BIT_N, BITS_IUPAC, MAX_CLUSTERS, N_INIT, PF, ROWS_PER_CHUNK, VF, BatchEngine,
                      PartitioningError, SequenceCurationError, expand_sequences)
-from .msa import CODE_GAP, MSA, decode
+from .msa import CODE_GAP, decode
 
 KIND_LEAF, KIND_INTERVAL, KIND_CLUSTER = 0, 1, 2
 _ACGT = np.frombuffer(b"ACGT-RYKMSWN????", dtype=np.uint8)
@@ -25,10 +25,6 @@ _ACGT = np.frombuffer(b"ACGT-RYKMSWN????", dtype=np.uint8)
 
 def _excl_cumsum(x: np.ndarray) -> np.ndarray:
     return np.cumsum(x) - x
-
-
-def _seg_ids(lengths: np.ndarray) -> np.ndarray:
-    return np.repeat(np.arange(lengths.shape[0]), lengths)
 
 
 def _seg_arange(lengths: np.ndarray) -> np.ndarray:
@@ -55,8 +51,7 @@ class Growable:
     def append(self, **cols):
         k = len(next(iter(cols.values())))
         for f, dt in self.fields.items():
-            v = cols.get(f)
-            self.chunks[f].append(np.full(k, -1, dt) if v is None else np.asarray(v, dtype=dt))
+            self.chunks[f].append(np.asarray(cols[f], dtype=dt))
         start = self.n
         self.n += k
         return np.arange(start, self.n)
@@ -66,10 +61,21 @@ class Growable:
 
 
 class ForestEngine(BatchEngine):
-    """load() as BatchEngine; run_forest() builds every tree of the batch with array-at-a-time host code."""
+    """load() as BatchEngine; run_forest() builds every tree of the batch; assemble_prgs() emits the PRG strings."""
 
+    # ------------------------------------------------------------------------------------------------ device row pool
+    def _pool_reserve(self, extra_rows: int):
+        need = 4 * (self.pool_used + extra_rows)
+        if need > self.pool_cap:
+            new_cap = max(2 * self.pool_cap, need, 1 << 16)
+            self.d_pool = self.be.grown(self.d_pool, 4 * self.pool_used, new_cap)
+            self.pool_cap = new_cap
+
+    def pool_host(self) -> np.ndarray:
+        return self.be.download(self.d_pool, np.int32, self.pool_used).astype(np.int64)
+
+    # ------------------------------------------------------------------------------------------------ forest
     def run_forest(self):
-        be = self.be
         M = len(self._msas)
         meta = np.asarray(self.meta, dtype=np.int64).reshape(M, 6)
         self.meta_arr = meta
@@ -77,26 +83,23 @@ class ForestEngine(BatchEngine):
         self.errors: Dict[int, Exception] = dict(self.bad)
         for i in self.bad:
             self.failed[i] = True
-        self.rl_pool = np.zeros(0, np.int64)      # all row lists of cluster children, concatenated
+        # row lists of cluster children live in one device pool; the host keeps only (offset, length) per list
+        self.pool_cap, self.pool_used = 0, 0
+        self.d_pool = self.be.empty(16)
         self.rl_off = np.zeros(0, np.int64)
         self.rl_len = np.zeros(0, np.int64)
-        self.levels: List[dict] = []          # per BFS level: node index range, cons, allgap
-        self.reps_pool: List[np.ndarray] = []  # leaf_mode 1: local row positions of distinct rows
-        self.reps_ulen_pool: List[np.ndarray] = []
-        self.reps_n = 0
+        self.levels: List[dict] = []
         T = Growable(dict(msa=np.int64, parent=np.int64, level=np.int64, rowlist=np.int64, col0=np.int64,
                           ncols=np.int64))
         self.T = T
-        # mutable per-node results (filled when the node's level is processed)
-        self.kind_c, self.first_child_c, self.n_child_c = [], [], []
-        self.lvl_c, self.col_off_c, self.leaf_mode_c, self.reps_off_c, self.reps_cnt_c = [], [], [], [], []
+        self.res_chunks: Dict[str, list] = {k: [] for k in ("kind", "first_child", "n_child", "lvl", "col_off", "leaf_mode",
+                                                            "reps_off", "nseq", "allele_chars", "node_level")}
         ok = np.nonzero(~self.failed)[0]
-        frontier = T.append(msa=ok, parent=np.full(len(ok), -1), level=np.zeros(len(ok), np.int64),
-                            rowlist=np.full(len(ok), -1), col0=np.zeros(len(ok), np.int64), ncols=meta[ok, 5])
+        cur = dict(msa=ok, parent=np.full(len(ok), -1, np.int64), level=np.zeros(len(ok), np.int64),
+                   rowlist=np.full(len(ok), -1, np.int64), col0=np.zeros(len(ok), np.int64), ncols=meta[ok, 5].copy())
+        cur["idx"] = T.append(**{k: cur[k] for k in T.fields})
         self.root_of = np.full(M, -1, np.int64)
-        self.root_of[ok] = frontier
-        cur = dict(msa=ok, parent=np.full(len(ok), -1), level=np.zeros(len(ok), np.int64),
-                   rowlist=np.full(len(ok), -1), col0=np.zeros(len(ok), np.int64), ncols=meta[ok, 5].copy(), idx=frontier)
+        self.root_of[ok] = cur["idx"]
         while len(cur["idx"]):
             self.counters["levels"] += 1
             cur = self._forest_level(cur)
@@ -114,24 +117,21 @@ class ForestEngine(BatchEngine):
         nrows = meta[m, 4].copy()
         rows_off = np.full(n, -1, np.int64)
         if has.any():
-            rows_off[has] = self.rl_off[rl[has]]          # offsets into the global pool (uploaded whole)
+            rows_off[has] = self.rl_off[rl[has]]          # offsets into the device row pool
             nrows[has] = self.rl_len[rl[has]]
-            rowidx = self.rl_pool.astype(np.int32)
-        else:
-            rowidx = np.zeros(1, np.int32)
         tab[:, 4], tab[:, 5], tab[:, 6], tab[:, 7] = rows_off, nrows, cur["col0"], cur["ncols"]
         tab[:, 8] = _excl_cumsum(cur["ncols"])
         tab[:, 9] = _excl_cumsum(nrows)
-        return tab, rowidx
+        return tab
 
     def _forest_level(self, cur):
         be, L = self.be, self.L
         n = len(cur["idx"])
-        tab, rowidx = self._view_table_arr(cur)
+        tab = self._view_table_arr(cur)
         total_cols = int(tab[:, 7].sum())
         cells = float((tab[:, 5] * tab[:, 7]).sum())
         self.counters["cells_all"] += cells
-        d_views, d_rowidx = be.upload(tab), be.upload(rowidx)
+        d_views, d_rowidx = be.upload(tab), self.d_pool
         work = self._mask_work(tab)
         d_work, d_mask = be.upload(work), be.zeros(4 * total_cols)
         be.call("mprg_column_masks", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work),
@@ -149,13 +149,11 @@ class ForestEngine(BatchEngine):
 
         mm = mask & ~np.uint32(BIT_N)
         single = (mm != 0) & ((mm & (mm - 1)) == 0) & ((mm & BITS_IUPAC) == 0) & (mm != BIT_GAP)
-        cons = np.full(total_cols, 255, np.uint8)
-        cons[single] = np.log2(mm[single]).astype(np.uint8)
         lvl = len(self.levels)
-        self.levels.append(dict(cons=cons, allgap=(mask == BIT_GAP), special=(mask & np.uint32(BITS_IUPAC | BIT_N)) != 0))
+        self.levels.append(dict(allgap=(mask == BIT_GAP), special=(mask & np.uint32(BITS_IUPAC | BIT_N)) != 0,
+                                idx=cur["idx"]))
 
-        # failures (per-locus policy: the locus is dropped, the batch goes on)
-        if status.any():
+        if status.any():          # per-locus policy: the locus is dropped, the batch goes on
             for j in np.nonzero(status)[0]:
                 mi = int(cur["msa"][j])
                 if not self.failed[mi]:
@@ -168,19 +166,22 @@ class ForestEngine(BatchEngine):
         is_leaf = alive & (n_iv == 1) & (first_type == 0)
         is_interval = alive & ~is_leaf & ((n_iv > 1) | (cur["parent"] < 0))
         is_cand = alive & ~is_leaf & ~is_interval
-        has_star = _seg_sum((cons == 255).astype(np.int64), tab[:, 7]) > 0
+        has_star = _seg_sum((~single).astype(np.int64), tab[:, 7]) > 0
 
-        kind = np.full(n, KIND_LEAF, np.int8)
-        kind[is_interval] = KIND_INTERVAL
-        leaf_mode = np.zeros(n, np.int8)
-        leaf_mode[is_leaf & has_star] = 1
-        first_child = np.full(n, -1, np.int64)
-        n_child = np.zeros(n, np.int64)
-        reps_off = np.full(n, -1, np.int64)
-        reps_cnt = np.zeros(n, np.int64)
-        node_level = cur["level"].copy()
+        R = dict(kind=np.full(n, KIND_LEAF, np.int8), first_child=np.full(n, -1, np.int64), n_child=np.zeros(n, np.int64),
+                 lvl=np.full(n, lvl, np.int64), col_off=col_off.copy(), leaf_mode=np.zeros(n, np.int8),
+                 reps_off=np.full(n, -1, np.int64), nseq=np.ones(n, np.int64), allele_chars=cur["ncols"].copy(),
+                 node_level=cur["level"].copy())
+        R["kind"][is_interval] = KIND_INTERVAL
+        nxt = {k: [] for k in ("msa", "parent", "level", "rowlist", "col0", "ncols", "idx")}
 
-        nxt = dict(msa=[], parent=[], level=[], rowlist=[], col0=[], ncols=[], idx=[])
+        def add_children(par, rowlist, col0, ncols, level):
+            cols = dict(msa=cur["msa"][par], parent=cur["idx"][par], level=level, rowlist=rowlist, col0=col0, ncols=ncols)
+            idx = self.T.append(**cols)
+            for k, v in cols.items():
+                nxt[k].append(v)
+            nxt["idx"].append(idx)
+            return idx
 
         # ---- children of multi-interval nodes: one child per interval, same rows (recursion_tree.py:439-451)
         if is_interval.any():
@@ -188,147 +189,90 @@ class ForestEngine(BatchEngine):
             cnt = n_iv[pj]
             src = np.repeat(col_off[pj], cnt) + _seg_arange(cnt)
             par = np.repeat(pj, cnt)
-            c_col0 = cur["col0"][par] + iv[src, 0]
-            c_ncols = iv[src, 1] - iv[src, 0] + 1
-            idx = self.T.append(msa=cur["msa"][par], parent=cur["idx"][par], level=cur["level"][par],
-                                rowlist=cur["rowlist"][par], col0=c_col0, ncols=c_ncols)
-            first_child[pj] = idx[0] + _excl_cumsum(cnt)
-            n_child[pj] = cnt
-            for key, val in (("msa", cur["msa"][par]), ("parent", cur["idx"][par]), ("level", cur["level"][par]),
-                             ("rowlist", cur["rowlist"][par]), ("col0", c_col0), ("ncols", c_ncols), ("idx", idx)):
-                nxt[key].append(val)
+            idx = add_children(par, cur["rowlist"][par], cur["col0"][par] + iv[src, 0], iv[src, 1] - iv[src, 0] + 1,
+                               cur["level"][par])
+            R["first_child"][pj] = idx[0] + _excl_cumsum(cnt)
+            R["n_child"][pj] = cnt
 
         # ---- clustering stage (single non-match interval below a non-root node) + row groups of non-trivial leaves
         cands = np.nonzero(is_cand)[0]
         dleaves = np.nonzero(is_leaf & has_star)[0]
         if len(cands) or len(dleaves):
-            self._forest_cluster(cur, tab, d_views, d_rowidx, cands, dleaves, kind, leaf_mode, first_child, n_child,
-                                 reps_off, reps_cnt, node_level, nxt)
-
-        self.kind_c.append(kind); self.first_child_c.append(first_child); self.n_child_c.append(n_child)
-        self.lvl_c.append(np.full(n, lvl, np.int64)); self.col_off_c.append(col_off.copy())
-        self.leaf_mode_c.append(leaf_mode); self.reps_off_c.append(reps_off); self.reps_cnt_c.append(reps_cnt)
-        self.levels[lvl]["node_level"] = node_level
-        self.levels[lvl]["idx"] = cur["idx"]
-        out = {k: (np.concatenate(v) if v else np.zeros(0, np.int64)) for k, v in nxt.items()}
-        return out
+            self._forest_cluster(cur, tab, d_views, cands, dleaves, R, add_children, lvl)
+        for k, v in R.items():
+            self.res_chunks[k].append(v)
+        return {k: (np.concatenate(v) if v else np.zeros(0, np.int64)) for k, v in nxt.items()}
 
     # ------------------------------------------------------------------------------------------------ clustering
-    def _forest_cluster(self, cur, tab, d_views, d_rowidx, cands, dleaves, kind, leaf_mode, first_child, n_child,
-                        reps_off, reps_cnt, node_level, nxt):
+    def _forest_cluster(self, cur, tab, d_views, cands, dleaves, R, add_children, lvl):
         be, K = self.be, self.L
         sel = np.concatenate([cands, dleaves])
-        ncand = len(cands)
+        ncand, nsel = len(cands), len(cands) + len(dleaves)
         sub = tab[sel].copy()
         S = sub[:, 5]
-        pad_rows = (S + 15) // 16 * 16
-        usize = sub[:, 7] * pad_rows
+        usize = sub[:, 7] * ((S + 15) // 16 * 16)
         sub[:, 10] = _excl_cumsum(usize)
         sub[:, 9] = _excl_cumsum(S)
         sub[:, 8] = _excl_cumsum(sub[:, 7])
-        R, tot_u, tot_cols = int(S.sum()), int(usize.sum()), int(sub[:, 7].sum())
-        d_sub = be.upload(sub)
-        d_ucodes, d_hash = be.empty(tot_u), be.empty(16 * R)
-        d_ulen, d_repu, d_repg = be.empty(4 * R), be.empty(4 * R), be.empty(4 * R)
-        be.call("mprg_ungap_dedupe", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), len(sel), be.ptr(d_ucodes),
-                be.ptr(d_hash), be.ptr(d_ulen), be.ptr(d_repu), be.ptr(d_repg), be.stream,
-                work=2.0 * float((S * sub[:, 7]).sum()))
-        self.counters["launches"] += 1
-        ulen = be.download(d_ulen, np.int32, R).astype(np.int64)
-        rep_u = be.download(d_repu, np.int32, R).astype(np.int64)
-        rep_g = be.download(d_repg, np.int32, R).astype(np.int64)
-
-        seg_start = sub[:, 9]
-        row_view = _seg_ids(S)
-        local = np.arange(R) - seg_start[row_view]
-        is_rep = rep_u == local
-        n_uu = _seg_sum(is_rep.astype(np.int64), S)
-        n_ug = _seg_sum((rep_g == local).astype(np.int64), S)
-        # every selected view records its distinct rows (leaf emission, recursion_tree.py:272-274)
-        self.reps_pool.append(local[is_rep])
-        self.reps_ulen_pool.append(ulen[is_rep])
-        reps_off[sel] = self.reps_n + _excl_cumsum(n_uu)
-        reps_cnt[sel] = n_uu
-        self.reps_n += int(n_uu.sum())
-        leaf_mode[sel] = 1
+        tot_rows, tot_u, tot_cols = int(S.sum()), int(usize.sum()), int(sub[:, 7].sum())
+        d_sub, d_rowidx = be.upload(sub), self.d_pool
+        dd = self._dedupe(d_sub, d_rowidx, nsel, tot_rows, tot_u, work=2.0 * float((S * sub[:, 7]).sum()))
+        sm = be.download(dd["summary"], np.int64, 8 * nsel).reshape(nsel, 8)
+        n_uu, n_ug, Dq, Tq, sumlen, nshort = (sm[:, i] for i in range(6))
+        # every selected view can end as a leaf whose alleles are its distinct rows (recursion_tree.py:272-274): the
+        # device keeps the first-appearance lists of this level; the host keeps where they are and how big
+        self.levels[lvl]["reps_pos"], self.levels[lvl]["reps_len"] = dd["reps_pos"], dd["reps_len"]
+        self.levels[lvl]["reps_rows"] = tot_rows
+        R["leaf_mode"][sel] = 1
+        R["reps_off"][sel] = sub[:, 9]
+        R["nseq"][sel] = n_uu
+        R["allele_chars"][sel] = sumlen
         if ncand == 0:
             return
         self.counters["cells_clustered"] += float((S[:ncand] * sub[:ncand, 7]).sum())
-        iscand_view = np.arange(len(sel)) < ncand
         lvl_c = cur["level"][sel]
-        long_rep = is_rep & (ulen >= K)
-        Dq = _seg_sum(long_rep.astype(np.int64), S)
+        # recursion_tree.py:538-556 / :475-494 and cluster_sequences.py:235-246: when the result cannot be used
         leaf_now = (lvl_c + 1 >= self.max_nesting) | (n_uu <= 2) | (n_uu < n_ug) | (Dq <= 2)
-        isprob_view = iscand_view & ~leaf_now
-        pq = np.nonzero(isprob_view)[0]
+        pq = np.nonzero((np.arange(nsel) < ncand) & ~leaf_now)[0]
         P = len(pq)
         if P == 0:
             return
-        # ---- problems (vectorised over all of them)
-        prob_of_view = np.full(len(sel), -1, np.int64)
-        prob_of_view[pq] = np.arange(P)
-        D = Dq[pq]
-        lr_mask = long_rep & isprob_view[row_view]
-        lr_rows = np.nonzero(lr_mask)[0]                        # global row index of every long rep, problem-major
-        seqrow = local[lr_rows].astype(np.int32)
+        D, Tp = Dq[pq], Tq[pq]
         so = _excl_cumsum(D)
-        occ = ulen[lr_rows] - K + 1
-        Tq = _seg_sum(occ, D)
-        prob_of_lr = _seg_ids(D)
-        occ_cum = np.cumsum(occ) - np.repeat(_excl_cumsum(Tq), D)      # inclusive cumsum inside the problem
-        occ_off = np.zeros(int(D.sum()) + P, np.int64)
-        occ_off[np.arange(len(lr_rows)) + prob_of_lr + 1] = occ_cum
-        cap = np.left_shift(np.int64(1), np.ceil(np.log2(np.maximum(2 * Tq, 16))).astype(np.int64))
+        cap = np.left_shift(np.int64(1), np.ceil(np.log2(np.maximum(2 * Tp, 16))).astype(np.int64))
+        fsz = (Tp + 15) // 16 * 16
         ptab = np.zeros((P, PF), np.int64)
-        ptab[:, 0], ptab[:, 1], ptab[:, 2], ptab[:, 3] = pq, D, so, Tq
-        ptab[:, 4], ptab[:, 5], ptab[:, 6] = _excl_cumsum(16 * cap), cap, so + np.arange(P)
-        fsz = (Tq + 15) // 16 * 16
-        ptab[:, 11] = _excl_cumsum(fsz)
-        d_seqrow, d_occ = be.upload(seqrow), be.upload(occ_off)
+        ptab[:, 0], ptab[:, 1], ptab[:, 2], ptab[:, 3] = pq, D, sub[pq, 9], Tp
+        ptab[:, 4], ptab[:, 5], ptab[:, 6], ptab[:, 11] = _excl_cumsum(16 * cap), cap, sub[pq, 9] + pq, _excl_cumsum(fsz)
         d_table, d_flag, d_V = be.empty(int((16 * cap).sum())), be.empty(int(fsz.sum())), be.empty(4 * P)
         d_ptab = be.upload(ptab)
-        be.call("mprg_kmer_dictionary", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(d_ucodes), be.ptr(d_ulen),
-                be.ptr(d_seqrow), be.ptr(d_occ), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), be.stream)
+        be.call("mprg_kmer_dictionary", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
+                be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), be.stream)
         V = be.download(d_V, np.int32, P).astype(np.int64)
-        ptab[:, 7] = V
-        ptab[:, 8] = _excl_cumsum(D * V)
         wsz = D * V + 2 * V + D + 8 + N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)   # mprg_kmeans_workspace_doubles
-        ptab[:, 9] = _excl_cumsum(wsz)
-        ptab[:, 10] = so
+        ptab[:, 7], ptab[:, 8], ptab[:, 9], ptab[:, 10] = V, _excl_cumsum(D * V), _excl_cumsum(wsz), so
         lo = int(D.sum())
         d_ptab = be.upload(ptab)
         d_x, d_ws = be.zeros(8 * int((D * V).sum())), be.empty(8 * int(wsz.sum()))
-        d_labels, d_info = be.empty(4 * lo), be.empty(64 * P)
-        be.call("mprg_kmer_counts", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(d_ucodes), be.ptr(d_ulen),
-                be.ptr(d_seqrow), be.ptr(d_occ), be.ptr(d_table), be.ptr(d_x), be.stream)
+        d_labels, d_assign, d_info = be.empty(4 * lo), be.zeros(4 * lo), be.empty(64 * P)
+        be.call("mprg_kmer_counts", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
+                be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_x), be.stream)
         be.call("mprg_kmeans_prepare", be.ptr(d_ptab), P, be.ptr(d_x), be.ptr(d_ws), be.stream)
         self.counters["launches"] += 3
-
-        # rows of problem views: distinct-sequence index of every row, member key (cluster_sequences.py:252-274)
-        prow = np.nonzero(isprob_view[row_view])[0]              # global rows of problem views
-        long_cum = np.cumsum(long_rep) - long_rep                 # exclusive count of long reps (global)
-        d_of_rep = np.where(long_rep, long_cum - long_cum[seg_start[row_view]], -1)
-        d_of_row = d_of_rep[seg_start[row_view] + rep_u]          # -1: row's sequence is shorter than k
-        order = np.lexsort((local, d_of_row, row_view))
-        mkey = np.empty(R, np.int64)
-        mkey[order] = np.arange(R) - seg_start[row_view[order]]
-        member = (d_of_row >= 0) & isprob_view[row_view]
-        mlabel = np.where(member, 0, -1).astype(np.int32)
-        d_mkey = be.upload(mkey.astype(np.int32))
         d_scratch, d_further = be.empty(12 * tot_cols + 64), be.empty(4 * P)
-        prob_of_row = prob_of_view[row_view]
-        label_idx = np.where(member, so[np.maximum(prob_of_row, 0)] + np.maximum(d_of_row, 0), 0)
 
         def check(act, k):
-            d_sp, d_ml = be.upload(ptab[act]), be.upload(mlabel)
+            """cluster_further() of the listed problems on the labels the select step just wrote (k=1: one cluster);
+            the same launch commits those labels as the problems' accepted assignment."""
+            d_sp = be.upload(ptab[act])
             be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp), len(act),
-                    k, be.ptr(d_ml), be.ptr(d_mkey), be.ptr(d_scratch), be.ptr(d_further), be.stream)
+                    k, be.ptr(dd["d_of_row"]), be.ptr(d_labels) if k > 1 else None, be.ptr(d_assign) if k > 1 else None,
+                    be.ptr(d_scratch), be.ptr(d_further), be.stream)
             self.counters["launches"] += 1
             return be.download(d_further, np.int32, len(act)).astype(bool)
 
+        # cluster_sequences.py:256-274, all problems of the level in lock-step (k is the same for every active one)
         num_clusters = np.ones(P, np.int64)
-        assign = np.zeros(lo, np.int64)
-        prob_of_d = _seg_ids(D)
         active = np.arange(P)[check(np.arange(P), 1)]
         k = 1
         while len(active):
@@ -346,7 +290,6 @@ class ForestEngine(BatchEngine):
             self.counters["launches"] += 2
             st = be.download(d_st, np.int32, nA)
             info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
-            labels_all = be.download(d_labels, np.int32, lo).astype(np.int64)
             if st.any():
                 raise MprgError("KMeans hit an empty cluster (scikit-learn's relocation step is not implemented on "
                                 "the device); refusing to continue with a result that may differ from the reference")
@@ -359,101 +302,57 @@ class ForestEngine(BatchEngine):
             good = info[:, 3].astype(np.int64) >= k
             num_clusters[active[~good]] -= 1                     # cluster_sequences.py:267-273: revert and stop
             active = active[good]
-            if not len(active):
-                break
-            upd = np.zeros(P, bool)
-            upd[active] = True
-            dm = upd[prob_of_d]
-            assign[dm] = labels_all[dm]
-            rm = member & upd[np.maximum(prob_of_row, 0)]
-            mlabel[rm] = assign[label_idx[rm]]
-            active = active[check(active, k)]
+            if len(active):
+                active = active[check(active, k)]
 
-        # ---- results: cluster nodes with children, or leaves (cluster_sequences.py:276-296, recursion_tree.py:457-469)
+        # ---- MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
         splits = np.nonzero((num_clusters != 1) & (num_clusters != D))[0]
         if not len(splits):
             return
-        is_split = np.zeros(P, bool)
-        is_split[splits] = True
-        srow = np.nonzero(is_split[np.maximum(prob_of_row, 0)] & (prob_of_row >= 0))[0]   # rows of splitting views
-        kfin = np.zeros(P, np.int64)
-        np.maximum.at(kfin, prob_of_d, assign + 1)
-        short_rep = is_rep & (ulen < K)
-        short_cum = np.cumsum(short_rep) - short_rep
-        s_of_rep = np.where(short_rep, short_cum - short_cum[seg_start[row_view]], -1)
-        s_of_row = s_of_rep[seg_start[row_view] + rep_u]
-        crow = np.where(d_of_row >= 0, assign[label_idx], kfin[np.maximum(prob_of_row, 0)] + s_of_row)
-        # the cluster holding the first row goes first (merge_clusters), the others keep label / appearance order
-        c0 = np.zeros(P, np.int64)
-        first_rows = seg_start[pq]                                 # global row of local position 0 of each problem
-        c0[:] = crow[first_rows]
-        p_s, c_s, l_s = prob_of_row[srow], crow[srow], local[srow]
-        rank = np.where(c_s == c0[p_s], 0, np.where(c_s < c0[p_s], c_s + 1, c_s))
-        order = np.lexsort((l_s, rank, p_s))
-        p_o, r_o, l_o = p_s[order], rank[order], l_s[order]
-        newgrp = np.ones(len(order), bool)
-        newgrp[1:] = (p_o[1:] != p_o[:-1]) | (r_o[1:] != r_o[:-1])
-        gstart = np.nonzero(newgrp)[0]
-        glen = np.diff(np.concatenate((gstart, [len(order)])))
-        gprob = p_o[gstart]
-        # MSA row indices of the children (views with a row list map local positions through it)
-        vj = sel[pq[p_o]]                                          # frontier position of each sorted row's view
-        rl = cur["rowlist"][vj]
-        if len(self.rl_pool):
-            rows_abs = np.where(rl >= 0, self.rl_pool[np.where(rl >= 0, self.rl_off[np.maximum(rl, 0)] + l_o, 0)], l_o)
-        else:
-            rows_abs = l_o
+        kfin = np.minimum(num_clusters[splits], MAX_CLUSTERS)
+        nchild = kfin + nshort[pq[splits]]
+        S_sp = S[pq[splits]]
+        self._pool_reserve(int(S_sp.sum()))
+        pool_off = self.pool_used + _excl_cumsum(S_sp)
+        child_off = _excl_cumsum(nchild)
+        sp = np.stack([kfin, pool_off, child_off], axis=1).astype(np.int64)
+        d_sizes = be.empty(4 * int(nchild.sum()))
+        d_spt, d_spi = be.upload(ptab[splits]), be.upload(sp)
+        # rowidx (parents' lists) and pool_out (children's lists) are the same pool, disjoint regions
+        be.call("mprg_split_children", be.ptr(d_sub), be.ptr(self.d_pool), be.ptr(d_spt), len(splits), be.ptr(d_spi),
+                be.ptr(dd["d_of_row"]), be.ptr(dd["s_of_row"]), be.ptr(d_assign), be.ptr(self.d_pool), be.ptr(d_sizes),
+                be.stream)
+        self.counters["launches"] += 1
+        sizes = be.download(d_sizes, np.int32, int(nchild.sum())).astype(np.int64)
+        self.pool_used += int(S_sp.sum())
         base = len(self.rl_len)
-        self.rl_off = np.concatenate([self.rl_off, len(self.rl_pool) + gstart])
-        self.rl_len = np.concatenate([self.rl_len, glen])
-        self.rl_pool = np.concatenate([self.rl_pool, rows_abs])
-        par_j = sel[pq[gprob]]                                     # frontier position of the parent of every child
-        kind[sel[pq[splits]]] = KIND_CLUSTER
-        node_level[sel[pq[splits]]] += 1                           # recursion_tree.py:459
-        idx = self.T.append(msa=cur["msa"][par_j], parent=cur["idx"][par_j], level=node_level[par_j],
-                            rowlist=base + np.arange(len(gstart)), col0=cur["col0"][par_j], ncols=cur["ncols"][par_j])
-        nchild_p = np.bincount(gprob, minlength=P)[splits]
-        first_child[sel[pq[splits]]] = idx[0] + _excl_cumsum(nchild_p)
-        n_child[sel[pq[splits]]] = nchild_p
-        for key, val in (("msa", cur["msa"][par_j]), ("parent", cur["idx"][par_j]), ("level", node_level[par_j]),
-                         ("rowlist", base + np.arange(len(gstart))), ("col0", cur["col0"][par_j]),
-                         ("ncols", cur["ncols"][par_j]), ("idx", idx)):
-            nxt[key].append(val)
+        within = np.cumsum(sizes) - sizes - np.repeat(_excl_cumsum(S_sp), nchild)   # offset of a child inside its problem
+        self.rl_off = np.concatenate([self.rl_off, np.repeat(pool_off, nchild) + within])
+        self.rl_len = np.concatenate([self.rl_len, sizes])
+        pj = sel[pq[splits]]                                        # frontier positions of the new cluster nodes
+        R["kind"][pj] = KIND_CLUSTER
+        R["node_level"][pj] += 1                                    # recursion_tree.py:459
+        par = np.repeat(pj, nchild)
+        idx = add_children(par, base + np.arange(len(sizes)), cur["col0"][par], cur["ncols"][par], R["node_level"][par])
+        R["first_child"][pj] = idx[0] + child_off
+        R["n_child"][pj] = nchild
 
     # ------------------------------------------------------------------------------------------------ tables
     def _finalize_tables(self):
         t = self.T.finalize()
         n = self.T.n
         order = np.concatenate([lv["idx"] for lv in self.levels]) if self.levels else np.zeros(0, np.int64)
-
-        def scatter(chunks, dtype):
-            out = np.zeros(n, dtype)
+        for key, chunks in self.res_chunks.items():
+            out = np.zeros(n, chunks[0].dtype if chunks else np.int64)
             if chunks:
                 out[order] = np.concatenate(chunks)
-            return out
-
-        t["kind"] = scatter(self.kind_c, np.int8)
-        t["first_child"] = scatter(self.first_child_c, np.int64)
-        t["n_child"] = scatter(self.n_child_c, np.int64)
-        t["lvl"] = scatter(self.lvl_c, np.int64)
-        t["col_off"] = scatter(self.col_off_c, np.int64)
-        t["leaf_mode"] = scatter(self.leaf_mode_c, np.int8)
-        t["reps_off"] = scatter(self.reps_off_c, np.int64)
-        t["reps_cnt"] = scatter(self.reps_cnt_c, np.int64)
-        lev = np.zeros(n, np.int64)
-        if self.levels:
-            lev[order] = np.concatenate([lv["node_level"] for lv in self.levels])
-        t["level"] = lev
-        t["processed"] = np.zeros(n, bool)
-        t["processed"][order] = True
+            t[key] = out
+        t["level"] = t.pop("node_level")
         self.tab = t
-        self.reps = np.concatenate(self.reps_pool) if self.reps_pool else np.zeros(0, np.int64)
-        self.reps_ulen = np.concatenate(self.reps_ulen_pool) if self.reps_ulen_pool else np.zeros(0, np.int64)
-        self.special_all = np.concatenate([lv["special"] for lv in self.levels]) if self.levels else np.zeros(0, bool)
-        # the concatenated per-level column arrays (consensus codes, all-gap flags)
-        offs = _excl_cumsum(np.asarray([len(lv["cons"]) for lv in self.levels], dtype=np.int64)) if self.levels else np.zeros(0, np.int64)
-        self.cons_all = np.concatenate([lv["cons"] for lv in self.levels]) if self.levels else np.zeros(0, np.uint8)
-        self.allgap_all = np.concatenate([lv["allgap"] for lv in self.levels]) if self.levels else np.zeros(0, bool)
+        widths = np.asarray([len(lv["allgap"]) for lv in self.levels], dtype=np.int64)
+        offs = _excl_cumsum(widths) if len(widths) else np.zeros(0, np.int64)
+        cat = (lambda key, dt: np.concatenate([lv[key] for lv in self.levels]) if self.levels else np.zeros(0, dt))
+        self.allgap_all, self.special_all = cat("allgap", bool), cat("special", bool)
         t["gcol_off"] = offs[t["lvl"]] + t["col_off"] if n else np.zeros(0, np.int64)
 
 
@@ -474,17 +373,43 @@ def _write_markers(buf: np.ndarray, pos: np.ndarray, val: np.ndarray):
     buf[pos + nd + 1] = 32
     for k in range(int(nd.max())):
         m = nd > k
-        # k-th digit from the left
-        div = 10 ** (nd[m] - 1 - k)
-        buf[pos[m] + 1 + k] = 48 + (val[m] // div) % 10
+        buf[pos[m] + 1 + k] = 48 + (val[m] // 10 ** (nd[m] - 1 - k)) % 10
+
+
+def _special_leaf_alleles(self: "ForestEngine", leaves: np.ndarray) -> Dict[int, List[str]]:
+    """Leaves whose columns contain ambiguity codes or N: IUPAC expansion on the host (utils/seq_utils.py:116-153).
+    Rare; fetches the leaf's distinct rows from the device lists."""
+    t = self.tab
+    pool = self.pool_host() if self.pool_used else np.zeros(0, np.int64)
+    out: Dict[int, List[str]] = {}
+    cache: Dict[int, np.ndarray] = {}
+    for lf in leaves.tolist():
+        lv = int(t["lvl"][lf])
+        if lv not in cache:
+            cache[lv] = self.be.download(self.levels[lv]["reps_pos"], np.int32, self.levels[lv]["reps_rows"]).astype(np.int64)
+        ro = int(t["reps_off"][lf])
+        rp = cache[lv][ro:ro + int(t["nseq"][lf])]
+        rl = int(t["rowlist"][lf])
+        rows = rp if rl < 0 else pool[self.rl_off[rl] + rp]
+        codes = self.codes[int(t["msa"][lf])]
+        block = codes[rows, int(t["col0"][lf]):int(t["col0"][lf]) + int(t["ncols"][lf])]
+        seqs = [_ACGT[r[r != CODE_GAP]].tobytes().decode() for r in block]
+        try:
+            out[lf] = expand_sequences(seqs)
+        except SequenceCurationError as err:
+            mi = int(t["msa"][lf])
+            self.failed[mi] = True
+            self.errors[mi] = err
+            out[lf] = ["A"]
+    return out
 
 
 def assemble_prgs(self: ForestEngine, want_index: bool = False):
     """PRG string of every alignment of the batch (None for loci dropped by the curation policy).
-    Host, array-at-a-time: preorder ranks and site numbers by prefix sums over the node table, text offsets by a
-    bottom-up length pass and a top-down start pass, site markers scattered with NumPy.  Device: the allele characters
-    themselves (mprg_emit_alleles copies the ungapped cells of every allele to its offset) — the PRG text is ~80 KB per
-    config-C alignment, so this is the byte-heavy part.
+    Host (per-node arrays only): preorder ranks and site numbers by prefix sums over the node table, text lengths
+    bottom-up, text offsets top-down, cluster-node site markers.  Device: every leaf's alleles and its own markers
+    (mprg_leaf_jobs turns leaves into copy jobs from the first-appearance lists, mprg_emit_alleles copies the ungapped
+    cells) — the PRG text is ~80 KB per config-C alignment, so this is the byte-heavy part.
     reference: PrgBuilder.build_prg prg_builder.py:100-105; traversals recursion_tree.py:194-201, :222-239, :266-300."""
     be = self.be
     t = self.tab
@@ -494,68 +419,23 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False):
         return [None] * M
     msa, parent, kind, nch, fch = t["msa"], t["parent"], t["kind"], t["n_child"], t["first_child"]
     meta = self.meta_arr
-    rl_off = self.rl_off if len(self.rl_off) else np.zeros(1, np.int64)
-    rl_pool = self.rl_pool if len(self.rl_pool) else np.zeros(1, np.int64)
-
-    def abs_rows(nodes_idx, local_pos):
-        rl = t["rowlist"][nodes_idx]
-        return np.where(rl >= 0, rl_pool[np.where(rl >= 0, rl_off[np.maximum(rl, 0)] + local_pos, 0)], local_pos)
-
     leaf_all = kind == KIND_LEAF
-    # ---- alleles: (leaf, source row) pairs ----------------------------------------------------------------------------
-    l0 = np.nonzero(leaf_all & (t["leaf_mode"] == 0))[0]           # one allele = any row (all rows equal, no gaps)
-    l1 = np.nonzero(leaf_all & (t["leaf_mode"] == 1))[0]           # alleles = the distinct ungapped rows
-    cnt1 = t["reps_cnt"][l1]
-    p_leaf = np.concatenate([l0, np.repeat(l1, cnt1)])
-    rep_idx = np.repeat(t["reps_off"][l1], cnt1) + _seg_arange(cnt1)
-    p_local = np.concatenate([np.zeros(len(l0), np.int64), self.reps[rep_idx]])
-    p_len = np.concatenate([t["ncols"][l0], self.reps_ulen[rep_idx]])
-    p_row = abs_rows(p_leaf, p_local)
-    pm = msa[p_leaf]
-    p_src = meta[pm, 0] + p_row * meta[pm, 2] + t["col0"][p_leaf]
-    p_w = t["ncols"][p_leaf]
-    host_chars: Dict[int, np.ndarray] = {}                          # pair index -> ASCII (host-expanded alleles)
-    # leaves containing ambiguity codes / N: expansion on the host (utils/seq_utils.py:116-153), rare
-    if len(l1):
-        sp_cols = np.concatenate(([0], np.cumsum(self.special_all)))
+    nseq = np.where(leaf_all, t["nseq"], 0)
+    achars = np.where(leaf_all, t["allele_chars"], 0)
+    # leaves with ambiguity codes / N in their columns: host expansion
+    host_leaf: Dict[int, List[str]] = {}
+    l1 = np.nonzero(leaf_all & (t["leaf_mode"] == 1))[0]
+    if len(l1) and self.special_all.any():
+        spc = np.concatenate(([0], np.cumsum(self.special_all)))
         g = t["gcol_off"][l1]
-        leaf_special = (sp_cols[g + t["ncols"][l1]] - sp_cols[g]) > 0
-        if leaf_special.any():
-            sp_set = set(l1[leaf_special].tolist())
-            keep = ~np.isin(p_leaf, l1[leaf_special])
-            extra_leaf, extra_len, extra_chars = [], [], []
-            for lf in sorted(sp_set):
-                sel = np.nonzero(p_leaf == lf)[0]
-                seqs = []
-                for i in sel:
-                    cells = self.host_arena[p_src[i]:p_src[i] + p_w[i]]
-                    seqs.append(_ACGT[cells[cells != CODE_GAP]].tobytes().decode())
-                try:
-                    seqs = expand_sequences(seqs)
-                except SequenceCurationError as err:
-                    mi = int(msa[lf])
-                    self.failed[mi] = True
-                    self.errors[mi] = err
-                    seqs = ["A"]
-                for q in seqs:
-                    extra_leaf.append(lf); extra_len.append(len(q)); extra_chars.append(np.frombuffer(q.encode(), np.uint8))
-            nkeep = int(keep.sum())
-            p_leaf = np.concatenate([p_leaf[keep], np.asarray(extra_leaf, np.int64)])
-            p_len = np.concatenate([p_len[keep], np.asarray(extra_len, np.int64)])
-            p_src = np.concatenate([p_src[keep], np.full(len(extra_leaf), -1, np.int64)])
-            p_w = np.concatenate([p_w[keep], np.zeros(len(extra_leaf), np.int64)])
-            for i, ch in enumerate(extra_chars):
-                host_chars[nkeep + i] = ch
-            o = np.argsort(p_leaf, kind="stable")
-            inv = np.empty(len(o), np.int64)
-            inv[o] = np.arange(len(o))
-            host_chars = {int(inv[i]): ch for i, ch in host_chars.items()}
-            p_leaf, p_len, p_src, p_w = p_leaf[o], p_len[o], p_src[o], p_w[o]
-        else:
-            o = np.argsort(p_leaf, kind="stable")
-            p_leaf, p_len, p_src, p_w = p_leaf[o], p_len[o], p_src[o], p_w[o]
+        sp_leaves = l1[(spc[g + t["ncols"][l1]] - spc[g]) > 0]
+        sp_leaves = sp_leaves[~self.failed[msa[sp_leaves]]]
+        if len(sp_leaves):
+            host_leaf = _special_leaf_alleles(self, sp_leaves)
+            for lf, seqs in host_leaf.items():
+                nseq[lf] = len(seqs)
+                achars[lf] = sum(len(q) for q in seqs)
     valid = ~self.failed[msa]
-    nseq = np.bincount(p_leaf, minlength=n).astype(np.int64)
     nseq[~valid] = 0
     is_leaf = leaf_all & valid
     # ---- preorder rank inside each tree ------------------------------------------------------------------------------
@@ -587,9 +467,7 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False):
     mid_len = np.where(opener, _digits(site + 1) + 2, 0)
     n_sites = np.bincount(msa[opener], minlength=M)
     # ---- text lengths bottom-up, starts top-down ---------------------------------------------------------------------
-    total = np.zeros(n, np.int64)
-    np.add.at(total, p_leaf, p_len)
-    total[~valid] = 0
+    total = np.where(is_leaf, achars, 0)
     multi = is_leaf & (nseq > 1)
     total[multi] += open_len[multi] * 2 + (nseq[multi] - 1) * mid_len[multi]
     clus = valid & (kind == KIND_CLUSTER)
@@ -615,43 +493,65 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False):
         x = total[idx] + np.where(pc, np.where(last, open_len[p], mid_len[p]), 0)
         c = np.cumsum(x) - x
         start[idx] = start[p] + open_len[p] * pc + c - c[fch[p] - idx[0]]
-    # ---- allele positions inside their leaves ----------------------------------------------------------------------------
-    npair = len(p_leaf)
-    newleaf = np.ones(npair, bool)
-    newleaf[1:] = p_leaf[1:] != p_leaf[:-1]
-    firstpair = np.nonzero(newleaf)[0]
-    k_in_leaf = np.arange(npair) - np.repeat(firstpair, np.diff(np.concatenate((firstpair, [npair]))))
-    is_multi = nseq[p_leaf] > 1
-    lastseq = k_in_leaf == nseq[p_leaf] - 1
-    x = p_len + np.where(is_multi, np.where(lastseq, open_len[p_leaf], mid_len[p_leaf]), 0)
-    c = np.cumsum(x) - x
-    spos = start[p_leaf] + np.where(is_multi, open_len[p_leaf], 0) + c - np.repeat(c[firstpair], np.diff(np.concatenate((firstpair, [npair]))))
-    okp = valid[p_leaf]
-    # ---- device: copy the allele characters ------------------------------------------------------------------------------
+    # ---- device: leaves -> allele copy jobs (+ the leaves' own markers) -> characters ------------------------------------
     total_chars = int(msa_len.sum())
-    dev = okp & (p_src >= 0)
-    jobs = np.stack([p_src[dev], p_w[dev], spos[dev]], axis=1).astype(np.int64)
     d_out = be.zeros(total_chars)
-    if len(jobs):
-        d_jobs = be.upload(jobs)
-        be.call("mprg_emit_alleles", be.ptr(self.d_arena), be.ptr(d_jobs), len(jobs), be.ptr(d_out), be.stream,
-                work=float(jobs[:, 1].sum() + p_len[dev].sum()))
+    dev_leaf = is_leaf.copy()
+    for lf in host_leaf:
+        dev_leaf[lf] = False
+    dl = np.nonzero(dev_leaf)[0]
+    job_off = _excl_cumsum(nseq[dl])
+    n_jobs = int(nseq[dl].sum())
+    d_jobs = be.empty(32 * max(n_jobs, 1))
+    rl = t["rowlist"][dl]
+    ltab = np.zeros((len(dl), 10), np.int64)
+    ltab[:, 0], ltab[:, 1] = meta[msa[dl], 0], meta[msa[dl], 2]
+    ltab[:, 2] = np.where(rl >= 0, self.rl_off[np.maximum(rl, 0)], -1) if len(self.rl_off) else -1
+    ltab[:, 3], ltab[:, 4] = t["col0"][dl], t["ncols"][dl]
+    ltab[:, 5] = np.where(t["leaf_mode"][dl] == 1, t["reps_off"][dl], -1)
+    ltab[:, 6], ltab[:, 7], ltab[:, 8], ltab[:, 9] = nseq[dl], start[dl], np.where(nseq[dl] > 1, site[dl], 0), job_off
+    lv_of = np.where(t["leaf_mode"][dl] == 1, t["lvl"][dl], -1)         # -1: needs no level lists
+    keep_alive = []
+    for lv in np.unique(lv_of):
+        m = lv_of == lv
+        rp = self.levels[lv]["reps_pos"] if lv >= 0 else None
+        rn = self.levels[lv]["reps_len"] if lv >= 0 else None
+        d_lt = be.upload(ltab[m])
+        keep_alive.append(d_lt)
+        be.call("mprg_leaf_jobs", be.ptr(d_lt), int(m.sum()), be.ptr(self.d_pool),
+                be.ptr(rp) if rp is not None else None, be.ptr(rn) if rn is not None else None, be.ptr(d_jobs),
+                be.ptr(d_out), be.stream)
+        self.counters["launches"] += 1
+    if n_jobs:
+        be.call("mprg_emit_alleles", be.ptr(self.d_arena), be.ptr(d_jobs), n_jobs, be.ptr(d_out), be.stream,
+                work=float((nseq[dl] * t["ncols"][dl]).sum() + achars[dl].sum()))
         self.counters["launches"] += 1
     buf = be.download(d_out, np.uint8, total_chars).copy()
-    for i, chs in host_chars.items():
-        if okp[i]:
-            buf[spos[i]:spos[i] + len(chs)] = chs
-    # ---- host: site markers --------------------------------------------------------------------------------------------------
+    # ---- host: cluster-node markers, host-expanded leaves --------------------------------------------------------------------
     cn = np.nonzero(clus)[0]
     _write_markers(buf, start[cn], site[cn])
     ch = np.nonzero(valid & (parent >= 0) & (kind[np.maximum(parent, 0)] == KIND_CLUSTER))[0]
     if len(ch):
         p = parent[ch]
         _write_markers(buf, start[ch] + total[ch], np.where(ch == fch[p] + nch[p] - 1, site[p], site[p] + 1))
-    mo = np.nonzero(multi)[0]
-    _write_markers(buf, start[mo], site[mo])
-    mk = okp & is_multi
-    _write_markers(buf, spos[mk] + p_len[mk], np.where(lastseq[mk], site[p_leaf[mk]], site[p_leaf[mk]] + 1))
+    host_index = []
+    for lf, seqs in host_leaf.items():
+        if not valid[lf]:
+            continue
+        pos = int(start[lf])
+        many = len(seqs) > 1
+        if many:
+            mtxt = f" {site[lf]} ".encode()
+            buf[pos:pos + len(mtxt)] = np.frombuffer(mtxt, np.uint8)
+            pos += len(mtxt)
+        for i, q in enumerate(seqs):
+            buf[pos:pos + len(q)] = np.frombuffer(q.encode(), np.uint8)
+            host_index.append((lf, pos - int(msa_base[msa[lf]]), pos - int(msa_base[msa[lf]]) + len(q)))
+            pos += len(q)
+            if many:
+                mtxt = f" {site[lf] + 1 if i < len(seqs) - 1 else site[lf]} ".encode()
+                buf[pos:pos + len(mtxt)] = np.frombuffer(mtxt, np.uint8)
+                pos += len(mtxt)
     out: List[Optional[str]] = [None] * M
     whole = buf.tobytes()
     for i in np.nonzero(~self.failed)[0]:
@@ -659,8 +559,13 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False):
     self.node_id = pre
     self.site_count = n_sites
     if want_index:      # prg_index: every allele of every leaf (recursion_tree.py:276-300)
-        self.prg_index_arrays = (p_leaf[okp], spos[okp] - msa_base[msa[p_leaf[okp]]],
-                                 spos[okp] - msa_base[msa[p_leaf[okp]]] + p_len[okp])
+        jobs = be.download(d_jobs, np.int64, 4 * n_jobs).reshape(-1, 4)
+        jl = np.repeat(dl, nseq[dl])
+        js = jobs[:, 2] - msa_base[msa[jl]]
+        leaf = np.concatenate([jl, np.asarray([h[0] for h in host_index], np.int64)])
+        s0 = np.concatenate([js, np.asarray([h[1] for h in host_index], np.int64)])
+        s1 = np.concatenate([js + jobs[:, 3], np.asarray([h[2] for h in host_index], np.int64)])
+        self.prg_index_arrays = (leaf, s0, s1)
     return out
 
 
@@ -672,12 +577,15 @@ def forest_tree_dump(self: ForestEngine, mi: int, ids: List[str]) -> list:
     t = self.tab
     codes = self.codes[mi]
     kinds = {KIND_LEAF: "leaf", KIND_INTERVAL: "interval", KIND_CLUSTER: "cluster"}
+    if getattr(self, "_pool_cache_used", -1) != self.pool_used:
+        self._pool_cache, self._pool_cache_used = self.pool_host(), self.pool_used
+    pool = self._pool_cache
     out = []
     stack = [int(self.root_of[mi])]
     while stack:
         ni = stack.pop()
         rl = int(t["rowlist"][ni])
-        rows = np.arange(codes.shape[0]) if rl < 0 else self.rl_pool[self.rl_off[rl]:self.rl_off[rl] + self.rl_len[rl]]
+        rows = np.arange(codes.shape[0]) if rl < 0 else pool[self.rl_off[rl]:self.rl_off[rl] + self.rl_len[rl]]
         c0, w, g = int(t["col0"][ni]), int(t["ncols"][ni]), int(t["gcol_off"][ni])
         keep = ~self.allgap_all[g:g + w]
         block = decode(codes[rows, c0:c0 + w][:, keep])

@@ -54,5 +54,10 @@ class EmuBackend(_Base):
     def ptr(self, buf):
         return buf.ctypes.data
 
+    def grown(self, buf, used_bytes, new_bytes):
+        new = np.full(int(new_bytes), 0xA5, np.uint8)
+        new[:used_bytes] = buf[:used_bytes]
+        return new
+
     def synchronize(self):
         pass

@@ -1,0 +1,26 @@
+"""Small GPU-box helper: run bench.py under a few environment / flag variants and print one line each."""
+import json
+import os
+import subprocess
+import sys
+
+variants = [
+    ("km64", {"MPRG_KM_THREADS": "64"}, ["--streams", "1"]),
+    ("km128", {"MPRG_KM_THREADS": "128"}, ["--streams", "1"]),
+    ("km256", {"MPRG_KM_THREADS": "256"}, ["--streams", "1"]),
+    ("km64x8", {"MPRG_KM_THREADS": "64"}, ["--streams", "8"]),
+    ("km128x8", {"MPRG_KM_THREADS": "128"}, ["--streams", "8"]),
+    ("km256x8", {"MPRG_KM_THREADS": "256"}, ["--streams", "8"]),
+]
+if len(sys.argv) > 1:
+    variants = [v for v in variants if v[0] in sys.argv[1:]]
+for name, env, flags in variants:
+    out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--steps", "2", "--warmup", "1"] + flags,
+                         env=dict(os.environ, **env), capture_output=True, text=True).stdout.strip().splitlines()
+    try:
+        d = json.loads(out[-1])
+        k = d["config"]["kernels"]
+        print(name, "value", d["value"], "ms/step", d["ms_per_step"], "dev_ms", d["config"]["device_ms_per_step"],
+              "restarts", k["mprg_kmeans_restarts"], flush=True)
+    except Exception as e:  # noqa
+        print(name, "FAILED", e, out[-3:], flush=True)
