@@ -120,7 +120,8 @@ int mprg_kmeans_restarts(const int64_t *prob, int n_probs, int k, int n_init, co
   if (n_probs <= 0) return 0;
   if (k < 2 || k > KM_KMAX) return fail("k must be in 2..10");
   const int n_trials = 2 + (int)log((double)k);
-  LAUNCH(k_kmeans_restart, n_probs * n_init, env_threads("MPRG_KM_THREADS", 256), stream, prob, k, n_init, n_trials, uniforms_dev, ws, km_status);
+  if (n_init > KM_RMAX) return fail("n_init must be <= 16");
+  LAUNCH(k_kmeans_restart, n_probs, env_threads("MPRG_KM_THREADS", 256), stream, prob, k, n_init, n_trials, uniforms_dev, ws, km_status);
   return check_launch("k_kmeans_restart");
 }
 

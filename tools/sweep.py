@@ -11,6 +11,19 @@ variants = [
     ("km64x8", {"MPRG_KM_THREADS": "64"}, ["--streams", "8"]),
     ("km128x8", {"MPRG_KM_THREADS": "128"}, ["--streams", "8"]),
     ("km256x8", {"MPRG_KM_THREADS": "256"}, ["--streams", "8"]),
+    ("s1", {"MPRG_KM_THREADS": "128"}, ["--streams", "1"]),
+    ("s2", {"MPRG_KM_THREADS": "128"}, ["--streams", "2"]),
+    ("s3", {"MPRG_KM_THREADS": "128"}, ["--streams", "3"]),
+    ("s4", {"MPRG_KM_THREADS": "128"}, ["--streams", "4"]),
+    ("s2b4k", {"MPRG_KM_THREADS": "128"}, ["--streams", "2", "--batch", "4096"]),
+    ("s1b4k", {"MPRG_KM_THREADS": "128"}, ["--streams", "1", "--batch", "4096"]),
+    ("s2k64", {"MPRG_KM_THREADS": "64"}, ["--streams", "2"]),
+    ("s1k256", {"MPRG_KM_THREADS": "256"}, ["--streams", "1"]),
+    ("s1k512", {"MPRG_KM_THREADS": "512"}, ["--streams", "1"]),
+    ("s1k1024", {"MPRG_KM_THREADS": "1024"}, ["--streams", "1"]),
+    ("s2k256", {"MPRG_KM_THREADS": "256"}, ["--streams", "2"]),
+    ("s3k256", {"MPRG_KM_THREADS": "256"}, ["--streams", "3"]),
+    ("s3k512", {"MPRG_KM_THREADS": "512"}, ["--streams", "3"]),
 ]
 if len(sys.argv) > 1:
     variants = [v for v in variants if v[0] in sys.argv[1:]]
