@@ -182,3 +182,28 @@ def materialise(eng: BatchEngine, res, alignment: MSA, prg_builder, parent_node=
         return node
 
     return make(res.root, parent_node)
+
+
+def materialise_forest(eng, mi: int, alignment: MSA, prg_builder) -> RecursiveTreeNode:
+    """Same as materialise() for one tree of a forest.ForestEngine batch (assemble_prgs() must have run)."""
+    from .forest import KIND_INTERVAL, KIND_LEAF
+    t = eng.tab
+    data = alignment.data
+    pool = eng.pool_host() if eng.pool_used else np.zeros(0, np.int64)
+
+    def make(ni: int, parent) -> RecursiveTreeNode:
+        rl = int(t["rowlist"][ni])
+        rows = np.arange(data.shape[0]) if rl < 0 else pool[eng.rl_off[rl]:eng.rl_off[rl] + eng.rl_len[rl]]
+        c0, w, g = int(t["col0"][ni]), int(t["ncols"][ni]), int(t["gcol_off"][ni])
+        keep = ~eng.allgap_all[g:g + w]
+        stored = MSA(_data=data[rows, c0:c0 + w][:, keep], _ids=[alignment.ids[r] for r in rows],
+                     _descs=[alignment.descriptions[r] for r in rows])
+        level, kind = int(t["level"][ni]), int(t["kind"][ni])
+        if kind == KIND_LEAF:
+            return LeafNode(level, stored, parent, prg_builder)
+        node = (MultiIntervalNode if kind == KIND_INTERVAL else MultiClusterNode)(level, stored, parent, prg_builder, [])
+        for j in range(int(t["n_child"][ni])):
+            node._children.append(make(int(t["first_child"][ni]) + j, node))
+        return node
+
+    return make(int(eng.root_of[mi]), None)

@@ -102,29 +102,53 @@ def build_shard(files: List[Path], options, backend=None) -> Dict[str, dict]:
     out: Dict[str, dict] = {}
     if not msas:
         return out
-    eng = BatchEngine(backend or get_backend(), options.max_nesting, options.min_match_length)
-    results = eng.build(msas)
+    be = backend or get_backend()
     ot = options.output_type
-    for locus, msa, res in zip(loci, msas, results):
-        try:
+
+    def emit(locus, msa, prg, root_factory):
+        logger.info(f"Writing output files of locus {locus}")
+        rec = dict(prg=prg)
+        if ot.prg:
+            builder = PrgBuilder(locus, None, options.alignment_format, options.max_nesting, options.min_match_length,
+                                 _root_factory=root_factory)
+            assert builder.build_prg() == prg
+            rec["pickle"] = pickle.dumps(builder, protocol=4)
+        if ot.binary:
+            enc = PrgEncoder()
+            rec["bin"] = np.asarray(enc.encode(prg), dtype="<u4").tobytes()
+        if ot.gfa:
+            rec["gfa"] = GFA_Output.gfa_text(prg).encode()
+        out[locus] = rec
+
+    # the array-at-a-time host assumes unique row ids inside an alignment; the rest keeps the id-based node host
+    uniq = [i for i, m in enumerate(msas) if len(set(m.ids)) == len(m.ids)]
+    dup = [i for i in range(len(msas)) if i not in set(uniq)]
+    if uniq:
+        from ..forest import ForestEngine
+        from ..recursion_tree import materialise_forest
+        eng = ForestEngine(be, options.max_nesting, options.min_match_length)
+        eng.load([msas[i] for i in uniq])
+        eng.run_forest()
+        prgs = eng.assemble_prgs()
+        for j, i in enumerate(uniq):
+            if prgs[j] is None:
+                err = eng.errors[j]
+                if not isinstance(err, SequenceCurationError):
+                    raise err
+                logger.warning(f"Skipping building PRG for {loci[i]}. Error: {err}")
+                continue
+            emit(loci[i], msas[i], prgs[j], lambda b, j=j, i=i: materialise_forest(eng, j, msas[i], b))
+    if dup:
+        eng2 = BatchEngine(be, options.max_nesting, options.min_match_length)
+        results = eng2.build([msas[i] for i in dup])
+        for i, res in zip(dup, results):
             if res.error is not None:
-                raise res.error
-            logger.info(f"Writing output files of locus {locus}")
-            prg, _, _ = build_prg(eng, res)
-            rec = dict(prg=prg)
-            if ot.prg:
-                builder = PrgBuilder(locus, None, options.alignment_format, options.max_nesting, options.min_match_length,
-                                     _root_factory=lambda b, res=res, msa=msa: materialise(eng, res, msa, b, None))
-                assert builder.build_prg() == prg
-                rec["pickle"] = pickle.dumps(builder, protocol=4)
-            if ot.binary:
-                enc = PrgEncoder()
-                rec["bin"] = np.asarray(enc.encode(prg), dtype="<u4").tobytes()
-            if ot.gfa:
-                rec["gfa"] = GFA_Output.gfa_text(prg).encode()
-            out[locus] = rec
-        except SequenceCurationError as err:
-            logger.warning(f"Skipping building PRG for {locus}. Error: {err}")
+                if not isinstance(res.error, SequenceCurationError):
+                    raise res.error
+                logger.warning(f"Skipping building PRG for {loci[i]}. Error: {res.error}")
+                continue
+            prg, _, _ = build_prg(eng2, res)
+            emit(loci[i], msas[i], prg, lambda b, res=res, i=i: materialise(eng2, res, msas[i], b, None))
     return out
 
 

@@ -52,3 +52,14 @@ def test_edge_cases_against_oracle(hip):
     from tests.edge_cases import EDGE_FASTAS
     for N, L, texts in EDGE_FASTAS:
         pc.check_vs_oracle(hip, texts, N, L)
+
+
+def test_random_small_alignments_against_oracle(hip):
+    from tests.random_msas import random_cases
+    for N, L, seed in [(5, 7, 31), (5, 3, 32), (2, 1, 33), (5, 2, 34)]:
+        pc.check_vs_oracle(hip, random_cases(seed, 200), N, L)
+
+
+def test_node_object_host_on_gpu(hip, golden_integration, monkeypatch):
+    monkeypatch.setattr(pc, "ENGINE", "nodes")
+    assert pc.check_integration(hip, golden_integration) >= 30
