@@ -39,7 +39,7 @@ enum { MPRG_IV_MATCH = 0, MPRG_IV_NONMATCH = 1 };
 /* per-view status bits written by mprg_partition */
 enum { MPRG_ST_PARTITION_ERROR = 1, MPRG_ST_ALL_N_SLICE = 2 };
 /* per-fit status bits written by the KMeans kernels */
-enum { MPRG_KM_EMPTY_CLUSTER = 1 };
+enum { MPRG_KM_RELOCATED = 1 /* an empty cluster was relocated (info) */, MPRG_KM_UNSUPPORTED = 2 /* error */ };
 
 const char *mprg_version(void);
 const char *mprg_last_error(void);

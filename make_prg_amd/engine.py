@@ -441,9 +441,9 @@ class BatchEngine:
             st = be.download(d_st, np.int32, nA)
             info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
             labels_all = be.download(d_labels, np.int32, lo)
-            if st.any():
-                raise MprgError("KMeans hit an empty cluster (scikit-learn's relocation step is not implemented on "
-                                "the device); refusing to continue with a result that may differ from the reference")
+            if (st & 2).any():
+                raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
+                                "is not restated on the device; refusing to continue with a possibly different result")
             nxt = []
             for a, i in enumerate(active):
                 p = probs[i]

@@ -290,9 +290,9 @@ class ForestEngine(BatchEngine):
             self.counters["launches"] += 2
             st = be.download(d_st, np.int32, nA)
             info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
-            if st.any():
-                raise MprgError("KMeans hit an empty cluster (scikit-learn's relocation step is not implemented on "
-                                "the device); refusing to continue with a result that may differ from the reference")
+            if (st & 2).any():
+                raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
+                                "is not restated on the device; refusing to continue with a possibly different result")
             kb = float((8.0 * D[active] * V[active] * (info[:, 4] + N_INIT)).sum())
             self.counters["fits"] += nA
             self.counters["kmeans_bytes"] += kb

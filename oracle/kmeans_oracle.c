@@ -316,6 +316,73 @@ static void kmeanspp(const km_t *p, mt_t *rs, double *centers, int *indices_out,
   }
 }
 
+/* NumPy arg-introselect (np.argpartition, float64, no NaNs): numpy/_core/src/npysort/selection.cpp.
+ * perm is permuted so that perm[kth] is in sorted position, smaller before, not-smaller after. */
+static void np_argpartition(const double *v, long *ts, long num, long kth) {
+#define LT(a, b) ((a) < (b))
+#define SWAPL(a, b) do { long t_ = (a); (a) = (b); (b) = t_; } while (0)
+  long low = 0, high = num - 1;
+  if (kth - low < 3) {                 /* dumb_select: O(n*kth) selection of the kth smallest */
+    for (long i = 0; i <= kth - low; i++) {
+      long minidx = i; double minval = v[ts[low + i]];
+      for (long k = i + 1; k < high - low + 1; k++)
+        if (LT(v[ts[low + k]], minval)) { minidx = k; minval = v[ts[low + k]]; }
+      SWAPL(ts[low + i], ts[low + minidx]);
+    }
+    return;
+  }
+  if (kth == num - 1) {                /* maximum to the end; the LAST of equal maxima wins */
+    long maxidx = low; double maxval = v[ts[low]];
+    for (long k = low + 1; k < num; k++)
+      if (!LT(v[ts[k]], maxval)) { maxidx = k; maxval = v[ts[k]]; }
+    SWAPL(ts[kth], ts[maxidx]);
+    return;
+  }
+  int depth_limit = 0;
+  { unsigned long n = (unsigned long)num; while (n >>= 1) depth_limit++; depth_limit *= 2; }
+  for (; low + 1 < high;) {
+    long ll = low + 1, hh = high;
+    if (depth_limit > 0 || hh - ll < 5) {
+      const long mid = low + (high - low) / 2;           /* median of 3, pivot to low, 3-lowest to low+1 */
+      if (LT(v[ts[high]], v[ts[mid]])) SWAPL(ts[high], ts[mid]);
+      if (LT(v[ts[high]], v[ts[low]])) SWAPL(ts[high], ts[low]);
+      if (LT(v[ts[low]], v[ts[mid]])) SWAPL(ts[low], ts[mid]);
+      SWAPL(ts[mid], ts[low + 1]);
+    } else {                                             /* median of medians of 5 (worst-case guard) */
+      long nmed = (hh - ll) / 5;
+      for (long i = 0, sub = ll; i < nmed; i++, sub += 5) {
+        long *t5 = ts + sub; const double *vv = v;
+        /* median5: sorting network on indices */
+        if (LT(vv[t5[1]], vv[t5[0]])) SWAPL(t5[1], t5[0]);
+        if (LT(vv[t5[4]], vv[t5[3]])) SWAPL(t5[4], t5[3]);
+        if (LT(vv[t5[3]], vv[t5[0]])) SWAPL(t5[3], t5[0]);
+        if (LT(vv[t5[4]], vv[t5[1]])) SWAPL(t5[4], t5[1]);
+        if (LT(vv[t5[2]], vv[t5[1]])) SWAPL(t5[2], t5[1]);
+        long m;
+        if (LT(vv[t5[3]], vv[t5[2]])) m = LT(vv[t5[3]], vv[t5[1]]) ? 1 : 3; else m = 2;
+        SWAPL(ts[sub + m], ts[ll + i]);
+      }
+      if (nmed > 2) np_argpartition(v, ts + ll, nmed, nmed / 2);
+      SWAPL(ts[ll + nmed / 2], ts[low]);
+      ll = low; hh = high + 1;
+    }
+    depth_limit--;
+    const double pivot = v[ts[low]];
+    for (;;) {                                           /* unguarded partition */
+      do ll++; while (LT(v[ts[ll]], pivot));
+      do hh--; while (LT(pivot, v[ts[hh]]));
+      if (hh < ll) break;
+      SWAPL(ts[hh], ts[ll]);
+    }
+    SWAPL(ts[low], ts[hh]);
+    if (hh >= kth) high = hh - 1;
+    if (hh <= kth) low = ll;
+  }
+  if (high == low + 1 && LT(v[ts[high]], v[ts[low]])) SWAPL(ts[high], ts[low]);
+#undef LT
+#undef SWAPL
+}
+
 /* _k_means_elkan.pyx:186-427 with n_threads = 1 */
 static int elkan_iter(const km_t *p, const double *cold, double *cnew, double *wic, const double *chd,
                       const double *dnext, double *ub, double *lb, int *labels, double *cshift, int update) {
@@ -368,14 +435,14 @@ static int elkan_iter(const km_t *p, const double *cold, double *cnew, double *w
         if (i == 0 || dist[i] > dmax) dmax = dist[i];
       }
       if (dmax != 0) {
-        /* far_from_centers = argpartition(dist, -n_empty)[:-n_empty-1:-1]: the n_empty largest, order as numpy's
-         * introselect leaves them.  Restated as "largest first, ties by higher index first" — flagged to callers
-         * through the `relocated` return so parity tests can single these cases out. */
+        /* far_from_centers = np.argpartition(dist, -n_empty)[:-n_empty-1:-1]: NumPy's arg-introselect
+         * (numpy/_core/src/npysort/selection.cpp) restated below; the tail of its permutation, reversed. */
+        long *perm = (long *)malloc(sizeof(long) * D);
+        for (int i = 0; i < D; i++) perm[i] = i;
+        np_argpartition(dist, perm, D, D - n_empty);
         char *used = (char *)calloc(D, 1);
         for (int e = 0; e < n_empty; e++) {
-          int far = -1;
-          for (int i = D - 1; i >= 0; i--) if (!used[i] && (far < 0 || dist[i] > dist[far])) far = i;
-          used[far] = 1;
+          int far = (int)perm[D - 1 - e];
           int newc = empty[e], oldc = labels[far];
           const double *xf = X + (size_t)far * V;
           for (int f = 0; f < V; f++) {
@@ -385,6 +452,7 @@ static int elkan_iter(const km_t *p, const double *cold, double *cnew, double *w
           wic[newc] = 1.0;
           wic[oldc] -= 1.0;
         }
+        free(perm);
         free(used);
       }
       free(dist); free(row);

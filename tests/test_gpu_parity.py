@@ -63,3 +63,8 @@ def test_random_small_alignments_against_oracle(hip):
 def test_node_object_host_on_gpu(hip, golden_integration, monkeypatch):
     monkeypatch.setattr(pc, "ENGINE", "nodes")
     assert pc.check_integration(hip, golden_integration) >= 30
+
+
+def test_empty_cluster_relocation_on_gpu(hip):
+    from tests.test_kmeans_relocation import check, degenerate_fits
+    check(hip, degenerate_fits(8, 80))

@@ -1,0 +1,34 @@
+"""Empty-cluster relocation (scikit-learn _relocate_empty_clusters_dense): degenerate count matrices (duplicate rows,
+k close to the number of distinct points) through the kernels' logic (emulation build) against the oracle.  The
+oracle's rule restates NumPy's generic arg-introselect, i.e. the reference's locked NumPy 1.24 (no SIMD sort)."""
+import numpy as np
+
+import oracle.from_msa_oracle as orc
+from tests.emu.backend import EmuBackend
+from tests.kmeans_direct import run_kmeans_fits
+
+
+def degenerate_fits(seed, n):
+    rng = np.random.default_rng(seed)
+    fits = []
+    while len(fits) < n:
+        D = int(rng.integers(4, 14)); V = int(rng.integers(1, 5)); k = int(rng.integers(2, min(D, 10)))
+        M = rng.integers(0, 3, (D, V)).astype(np.float64)
+        lab, dbg = orc.kmeans_fit_predict(M, k, want_debug=True)
+        if dbg["flags"] & 1:
+            fits.append(dict(shape=[D, V], counts_i16_hex=M.astype("<i2").tobytes().hex(), k=k, labels=lab.tolist(),
+                             inertia=float(dbg["inertia"]).hex(), n_iter=dbg["n_iter"]))
+    return fits
+
+
+def check(backend, fits):
+    got = run_kmeans_fits(backend, fits)
+    for g, f in zip(got, fits):
+        assert g["status"] & 1 and not g["status"] & 2
+        assert g["labels"] == f["labels"]
+        assert g["inertia_hex"] == f["inertia"]
+        assert g["n_iter"] == f["n_iter"]
+
+
+def test_relocation_matches_oracle():
+    check(EmuBackend(), degenerate_fits(7, 60))
