@@ -234,6 +234,25 @@ class ForestEngine(BatchEngine):
         # recursion_tree.py:538-556 / :475-494 and cluster_sequences.py:235-246: when the result cannot be used
         leaf_now = (lvl_c + 1 >= self.max_nesting) | (n_uu <= 2) | (n_uu < n_ug) | (Dq <= 2)
         pq = np.nonzero((np.arange(nsel) < ncand) & ~leaf_now)[0]
+        if len(pq) == 0:
+            return
+        d_scratch, d_further = be.empty(12 * tot_cols + 64), be.empty(4 * len(pq))
+
+        def check(act_tab, k, d_labels=None, d_assign=None):
+            """cluster_further() of the listed problems on the labels the select step just wrote (k=1: one cluster);
+            the same launch commits those labels as the problems' accepted assignment."""
+            d_sp = be.upload(act_tab)
+            be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp),
+                    len(act_tab), k, be.ptr(dd["d_of_row"]), be.ptr(d_labels) if k > 1 else None,
+                    be.ptr(d_assign) if k > 1 else None, be.ptr(d_scratch), be.ptr(d_further), be.stream)
+            self.counters["launches"] += 1
+            return be.download(d_further, np.int32, len(act_tab)).astype(bool)
+
+        # cluster_sequences.py:256: `while cluster_further(...)` is evaluated before any KMeans; a view whose rows are
+        # already one-reference-like never uses its k-mer matrix, so the featurisation is only done for the others
+        t1 = np.zeros((len(pq), PF), np.int64)
+        t1[:, 0], t1[:, 1] = pq, Dq[pq]
+        pq = pq[check(t1, 1)]
         P = len(pq)
         if P == 0:
             return
@@ -259,21 +278,9 @@ class ForestEngine(BatchEngine):
                 be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_x), be.stream)
         be.call("mprg_kmeans_prepare", be.ptr(d_ptab), P, be.ptr(d_x), be.ptr(d_ws), be.stream)
         self.counters["launches"] += 3
-        d_scratch, d_further = be.empty(12 * tot_cols + 64), be.empty(4 * P)
-
-        def check(act, k):
-            """cluster_further() of the listed problems on the labels the select step just wrote (k=1: one cluster);
-            the same launch commits those labels as the problems' accepted assignment."""
-            d_sp = be.upload(ptab[act])
-            be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp), len(act),
-                    k, be.ptr(dd["d_of_row"]), be.ptr(d_labels) if k > 1 else None, be.ptr(d_assign) if k > 1 else None,
-                    be.ptr(d_scratch), be.ptr(d_further), be.stream)
-            self.counters["launches"] += 1
-            return be.download(d_further, np.int32, len(act)).astype(bool)
-
         # cluster_sequences.py:256-274, all problems of the level in lock-step (k is the same for every active one)
         num_clusters = np.ones(P, np.int64)
-        active = np.arange(P)[check(np.arange(P), 1)]
+        active = np.arange(P)
         k = 1
         while len(active):
             k += 1
@@ -303,7 +310,7 @@ class ForestEngine(BatchEngine):
             num_clusters[active[~good]] -= 1                     # cluster_sequences.py:267-273: revert and stop
             active = active[good]
             if len(active):
-                active = active[check(active, k)]
+                active = active[check(ptab[active], k, d_labels, d_assign)]
 
         # ---- MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
         splits = np.nonzero((num_clusters != 1) & (num_clusters != D))[0]
