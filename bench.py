@@ -160,8 +160,18 @@ def main():
         name, d = dom
         launches = d["calls"]
         achieved = (d["bytes"] / max(d["ms"], 1e-9)) * 1e-6          # bytes/ms -> GB/s
+        # HBM traffic of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+        # gfx950 correction 2*FETCH+WRITE; tools/summarize_pmc.py): counters cannot be read inside this process, so the
+        # committed ratio traffic/algorithmic of the profiled run is applied to this run's algorithmic bytes per launch
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01b", "pmc_summary.json")))
+            ratio = pm["kernels"][{"mprg_kmeans_restarts": "k_kmeans_restart"}.get(name, name.replace("mprg_", "k_"))]["traffic_over_algorithmic"]
+            traffic = round(ratio * d["bytes"] / max(launches, 1), 1)
+        except Exception:
+            pass
         roof = dict(bound="hbm", kernel=name, achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic,
                     avg_launch_ms=round(d["ms"] / max(launches, 1), 4), launches=launches,
                     algorithmic_bytes_per_launch=round(d["bytes"] / max(launches, 1), 1))
         kernels = {k: dict(ms=round(v["ms"], 3), calls=v["calls"],
