@@ -119,13 +119,15 @@ int mprg_kmeans_select(const int64_t *prob, int n_probs, int k, int n_init, cons
 void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
 
 /* A10 — cluster_sequences.py:59-111 (majority string, Hamming distance, one-reference-like test, cluster_further).
- * One workgroup per problem.  A row takes part if d_of_row >= 0; its cluster is labels[prob[LABEL_OFF] + d_of_row]
- * (labels == NULL: a single cluster).  Ties in the per-column majority go to the symbol seen first in the order in
- * which the reference enumerates the cluster's rows (distinct sequence, then row).  If `assign` is given the labels
- * of these problems are also copied there (the fit is the accepted one).  out_further[n_probs] = 1 if some cluster is
- * not one-reference-like. */
+ * Two launches: majority strings per (problem, 256-column tile) — work_cols: n x 2 int32 {problem, tile} — then
+ * Hamming distances per (problem, 256-row chunk) — work_rows: n x 2 int32 {problem, chunk}.
+ * A row takes part if d_of_row >= 0; its cluster is labels[prob[LABEL_OFF] + d_of_row] (labels == NULL: a single
+ * cluster).  Ties in the per-column majority go to the symbol seen first in the order in which the reference enumerates
+ * the cluster's rows (distinct sequence, then row).  If `assign` is given the labels of these problems are also copied
+ * there (the fit is the accepted one).  out_further[n_probs] = 1 if some cluster is not one-reference-like. */
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
                          int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
+                         const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
                          int32_t *scratch, int32_t *out_further, void *stream);
 
 /* A12/A14 — cluster_sequences.py:287-296 + recursion_tree.py:558-572: row lists of the children of MultiClusterNodes.

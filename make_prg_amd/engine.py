@@ -134,12 +134,21 @@ class BatchEngine:
         return tab, rowidx, col_off, row_off
 
     @staticmethod
-    def _mask_work(tab: np.ndarray) -> np.ndarray:
-        """Work items {view, tile column, first row} of mprg_column_masks, vectorised over the views."""
+    def _mask_work(tab: np.ndarray, rows_per_chunk: Optional[int] = None):
+        """Work items {view, tile column, first row} of mprg_column_masks, vectorised over the views.
+        Returns (work, rows_per_chunk).  The row chunk is chosen so that a launch has >= ~1000 workgroups when the
+        level offers that much work (measured on MI355X: a 600 MB view streams at 4.9 TB/s with ~1200 workgroups of
+        512 rows x 1024 columns, 3.1 TB/s with 600, 1.2 TB/s with 18 000 tiny ones)."""
         n = tab.shape[0]
         lead = tab[:, 6] % 4                                  # col0 % 4: tiles start 4-aligned in arena columns
         ntile = (tab[:, 7] + lead + TILE_COLS - 1) // TILE_COLS
-        nchunk = (tab[:, 5] + ROWS_PER_CHUNK - 1) // ROWS_PER_CHUNK
+        if rows_per_chunk is None:
+            rows_per_chunk = 64
+            for rpc in (1024, 512, 256, 128):
+                if int((ntile * ((tab[:, 5] + rpc - 1) // rpc)).sum()) >= 1024:
+                    rows_per_chunk = rpc
+                    break
+        nchunk = (tab[:, 5] + rows_per_chunk - 1) // rows_per_chunk
         per = ntile * nchunk
         total = int(per.sum())
         view = np.repeat(np.arange(n), per)
@@ -151,8 +160,8 @@ class BatchEngine:
         work = np.empty((total, 3), np.int32)
         work[:, 0] = view
         work[:, 1] = tile * TILE_COLS - np.repeat(lead, per)
-        work[:, 2] = chunk * ROWS_PER_CHUNK
-        return work
+        work[:, 2] = chunk * rows_per_chunk
+        return work, rows_per_chunk
 
     # ------------------------------------------------------------------------------------------------ main entry
     def load(self, msas: List[MSA]):
@@ -209,11 +218,11 @@ class BatchEngine:
         cells = float((tab[:, 5] * tab[:, 7]).sum())
         d_views, d_rowidx = be.upload(tab), be.upload(rowidx)
         if given_mask is None:
-            work = self._mask_work(tab)
+            work, rpc = self._mask_work(tab)
             d_work = be.upload(work)
             d_mask = be.zeros(4 * total_cols)
             be.call("mprg_column_masks", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work),
-                    work.shape[0], ROWS_PER_CHUNK, be.ptr(d_mask), be.stream, work=cells)
+                    work.shape[0], rpc, be.ptr(d_mask), be.stream, work=cells)
         else:
             d_mask = be.upload(given_mask.astype(np.uint32))
         d_maxrun, d_stack, d_ivflag = be.zeros(4 * total_cols), be.empty(16 * total_cols), be.zeros(8 * total_cols)
@@ -278,6 +287,28 @@ class BatchEngine:
                                                      dedupe_leaves, results, failed))
         return next_frontier
 
+
+    def _cluster_further(self, d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further):
+        """mprg_cluster_further for the problems of act_tab (rows of the problem table); returns bool per problem."""
+        be = self.be
+        nA = len(act_tab)
+        views = act_tab[:, 0]
+        ncol_t = (sub[views, 7] + 255) // 256
+        nrow_t = (sub[views, 5] + 255) // 256
+
+        def items(cnt):
+            w = np.empty((int(cnt.sum()), 2), np.int32)
+            w[:, 0] = np.repeat(np.arange(nA), cnt)
+            w[:, 1] = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            return w
+
+        wc, wr = items(ncol_t), items(nrow_t)
+        d_sp, d_wc, d_wr = be.upload(act_tab), be.upload(wc), be.upload(wr)
+        be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp), nA, k,
+                be.ptr(d_dor), be.ptr(d_labels) if k > 1 else None, be.ptr(d_assign) if (k > 1 and d_assign is not None) else None,
+                be.ptr(d_wc), len(wc), be.ptr(d_wr), len(wr), be.ptr(d_scratch), be.ptr(d_further), be.stream)
+        self.counters["launches"] += 2
+        return be.download(d_further, np.int32, nA).astype(bool)
 
     def _dedupe(self, d_sub, d_rowidx, n_views: int, tot_rows: int, tot_u: int, work: float = 0.0):
         """mprg_ungap_dedupe over the views of `d_sub`; returns the device buffers by name."""
@@ -403,14 +434,9 @@ class BatchEngine:
         d_scratch, d_further = be.empty(12 * tot_cols + 64), be.empty(4 * P)
 
         def check(active_idx, k):
-            """cluster_further() for the listed problems with their current assignment (k clusters): the kernel reads
-            the labels the KMeans select step just wrote (k = 1: a single cluster)."""
-            d_sp = be.upload(ptab[active_idx])
-            be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp),
-                    len(active_idx), k, be.ptr(d_dor), be.ptr(d_labels) if k > 1 else None, None, be.ptr(d_scratch),
-                    be.ptr(d_further), be.stream)
-            self.counters["launches"] += 1
-            return be.download(d_further, np.int32, len(active_idx))
+            """cluster_further() for the listed problems on the labels the KMeans select step just wrote."""
+            return self._cluster_further(d_sub, d_rowidx, sub, ptab[active_idx], k, d_dor, d_labels, None, d_scratch,
+                                         d_further)
 
         active = list(range(P))
         fur = check(active, 1)
@@ -656,10 +682,10 @@ def _bm_column_masks(self: BatchEngine, alignment: MSA) -> np.ndarray:
     tab, rowidx, total_cols, _ = eng._view_table(nodes, [0])
     be = eng.be
     d_views, d_rowidx = be.upload(tab), be.upload(rowidx)
-    work = eng._mask_work(tab)
+    work, rpc = eng._mask_work(tab)
     d_work, d_mask = be.upload(work), be.zeros(4 * total_cols)
     be.call("mprg_column_masks", be.ptr(eng.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work), work.shape[0],
-            ROWS_PER_CHUNK, be.ptr(d_mask), be.stream)
+            rpc, be.ptr(d_mask), be.stream)
     return be.download(d_mask, np.uint32, total_cols)
 
 

@@ -132,10 +132,10 @@ class ForestEngine(BatchEngine):
         cells = float((tab[:, 5] * tab[:, 7]).sum())
         self.counters["cells_all"] += cells
         d_views, d_rowidx = be.upload(tab), self.d_pool
-        work = self._mask_work(tab)
+        work, rpc = self._mask_work(tab)
         d_work, d_mask = be.upload(work), be.zeros(4 * total_cols)
         be.call("mprg_column_masks", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work),
-                work.shape[0], ROWS_PER_CHUNK, be.ptr(d_mask), be.stream, work=cells)
+                work.shape[0], rpc, be.ptr(d_mask), be.stream, work=cells)
         d_maxrun, d_stack, d_ivflag = be.zeros(4 * total_cols), be.empty(16 * total_cols), be.zeros(8 * total_cols)
         d_iv, d_niv, d_status = be.empty(12 * total_cols), be.empty(4 * n), be.empty(4 * n)
         be.call("mprg_partition", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), n, be.ptr(d_mask), L,
@@ -240,13 +240,9 @@ class ForestEngine(BatchEngine):
 
         def check(act_tab, k, d_labels=None, d_assign=None):
             """cluster_further() of the listed problems on the labels the select step just wrote (k=1: one cluster);
-            the same launch commits those labels as the problems' accepted assignment."""
-            d_sp = be.upload(act_tab)
-            be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp),
-                    len(act_tab), k, be.ptr(dd["d_of_row"]), be.ptr(d_labels) if k > 1 else None,
-                    be.ptr(d_assign) if k > 1 else None, be.ptr(d_scratch), be.ptr(d_further), be.stream)
-            self.counters["launches"] += 1
-            return be.download(d_further, np.int32, len(act_tab)).astype(bool)
+            the same call commits those labels as the problems' accepted assignment."""
+            return self._cluster_further(d_sub, d_rowidx, sub, act_tab, k, dd["d_of_row"], d_labels, d_assign, d_scratch,
+                                         d_further)
 
         # cluster_sequences.py:256: `while cluster_further(...)` is evaluated before any KMeans; a view whose rows are
         # already one-reference-like never uses its k-mer matrix, so the featurisation is only done for the others

@@ -158,16 +158,17 @@ def read_fasta_alignment(text: str) -> MSA:
     return MSA(recs)
 
 
-def _majority_consensus(upper: np.ndarray) -> np.ndarray:
+def _majority_consensus(upper: np.ndarray, upto=None) -> np.ndarray:
     """utils/seq_utils.py:246-290: one Random(sha256(rows)) draw per column; choice among the most frequent
-    non-gap non-N residues in first-seen order, or among ACGT if the column has none."""
+    non-gap non-N residues in first-seen order, or among ACGT if the column has none.  Columns >= upto are not needed
+    by the caller (no N at or after them) and are left as 'A'."""
     rng = random.Random()
-    rng.seed(hashlib.sha256(upper.tobytes()).digest())
+    rng.seed(hashlib.sha256(np.ascontiguousarray(upper).tobytes()).digest())
     S, C = upper.shape
-    out = np.empty(C, np.uint8)
+    out = np.full(C, ord("A"), np.uint8)
     gap, n = ord("-"), ord("N")
     const_col = (upper == upper[0:1]).all(axis=0)
-    for c in range(C):
+    for c in range(C if upto is None else min(C, upto)):
         col = upper[:, c]
         if const_col[c] and col[0] != gap and col[0] != n:
             out[c] = ord(rng.choice([chr(col[0])]))
@@ -187,9 +188,10 @@ def load_alignment_text(text: str) -> MSA:
     data = msa.data.copy()
     lower = (data >= ord("a")) & (data <= ord("z"))
     data[lower] -= 32
-    cons = _majority_consensus(data)
     is_n = data == ord("N")
-    if is_n.any():
+    if is_n.any():          # the consensus is only ever used to overwrite N (io_utils.py:36-47): no N, no work
+        last = int(np.nonzero(is_n.any(axis=0))[0].max())
+        cons = _majority_consensus(data, upto=last + 1)     # the RNG stream must still advance column by column
         data[is_n] = np.broadcast_to(cons, data.shape)[is_n]
     return MSA(_data=data, _ids=msa.ids, _descs=msa.descriptions)
 
