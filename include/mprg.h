@@ -54,17 +54,20 @@ int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t 
                       int n_items, int rows_per_chunk, uint32_t *out_mask, void *stream);
 
 /* A3-A6 — from_msa/interval_partition.py:81-252 (IntervalPartitioner) with utils/seq_utils.py:37-42
- * (has_empty_sequence) and the <2-sequences test of :187-217.  One workgroup per view.
+ * (has_empty_sequence) and the <2-sequences test of :187-217.  Gap runs: one workgroup per (view, 256-row chunk)
+ * — work_rows: n x 2 int32 {view, chunk} —; the interval scan itself: one workgroup per view.
  * in:  mask (from mprg_column_masks), min_match_length.
  * scratch: maxrun uint32[total_cols] (zeroed), stack int32[4*total_cols], ivflag int32[total_cols*2] (zeroed)
  * out: iv int32[3*total_cols] as {start, stop, type} triples at 3*col_off, n_iv int32[n_views],
  *      status int32[n_views]. */
 int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
-                   const uint32_t *mask, int min_match_length, uint32_t *maxrun, int32_t *stack, int32_t *ivflag,
-                   int32_t *iv, int32_t *n_iv, int32_t *status, void *stream);
+                   const uint32_t *mask, int min_match_length, const int32_t *work_rows, int n_work_rows,
+                   uint32_t *maxrun, int32_t *stack, int32_t *ivflag, int32_t *iv, int32_t *n_iv, int32_t *status,
+                   void *stream);
 
 /* A9a/A13/A16 — from_msa/cluster_sequences.py:220-233 (ungap, group identical rows in first-appearance order),
- * utils/seq_utils.py:58-70 (unique gapped / ungapped counts).  One workgroup per view.
+ * utils/seq_utils.py:58-70 (unique gapped / ungapped counts).  Ungap + hash: one workgroup per (view, 256-row chunk)
+ * — work_rows: n x 2 int32 {view, chunk} —; grouping: one workgroup per view.
  * views[AUX0] = byte offset of this view's region in `ucodes` (n_cols * n_rows_pad bytes, n_rows_pad =
  * round_up(n_rows,16)); ungapped codes are stored transposed: character j of row position i at j*n_rows_pad + i.
  * per row (at row_off): ulen, rep_u (smallest row position with identical ungapped content), rep_g (same for gapped
@@ -76,9 +79,9 @@ int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *ro
  * summary int64[8*n_views] = {distinct ungapped, distinct gapped, D (distinct long), T (k-mer occurrences),
  * total ungapped length of the distinct rows, distinct short, 0, 0}.  scratch: hashes uint64[2*total_rows]. */
 int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views, int kmer_size,
-                      uint8_t *ucodes, uint64_t *hashes, int32_t *ulen, int32_t *rep_u, int32_t *rep_g,
-                      int32_t *d_of_row, int32_t *s_of_row, int32_t *reps_pos, int32_t *reps_len, int32_t *seqrow,
-                      int64_t *occ_off, int64_t *summary, void *stream);
+                      const int32_t *work_rows, int n_work_rows, uint8_t *ucodes, uint64_t *hashes, int32_t *ulen,
+                      int32_t *rep_u, int32_t *rep_g, int32_t *d_of_row, int32_t *s_of_row, int32_t *reps_pos,
+                      int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, void *stream);
 
 /* A9b — from_msa/cluster_sequences.py:26-38 (count_distinct_kmers): k-mer dictionary in first-appearance order.
  * One workgroup per clustering problem.  prob: n_probs x MPRG_PROB_FIELDS int64 (see enum).  seqrow int32[]:

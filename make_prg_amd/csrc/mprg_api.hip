@@ -65,19 +65,22 @@ int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t 
 }
 
 int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
-                   const uint32_t *mask, int min_match_length, uint32_t *maxrun, int32_t *stack, int32_t *ivflag,
-                   int32_t *iv, int32_t *n_iv, int32_t *status, void *stream) {
+                   const uint32_t *mask, int min_match_length, const int32_t *work_rows, int n_work_rows,
+                   uint32_t *maxrun, int32_t *stack, int32_t *ivflag, int32_t *iv, int32_t *n_iv, int32_t *status,
+                   void *stream) {
   if (n_views <= 0) return 0;
+  LAUNCH(k_gap_runs, n_work_rows, GR_ROWS, stream, arena, views, rowidx, work_rows, mask, maxrun);
   LAUNCH(k_partition, n_views, BLOCK_VIEW, stream, arena, views, rowidx, mask, min_match_length, maxrun, stack, ivflag,
          iv, n_iv, status);
   return check_launch("k_partition");
 }
 
 int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views, int kmer_size,
-                      uint8_t *ucodes, uint64_t *hashes, int32_t *ulen, int32_t *rep_u, int32_t *rep_g,
-                      int32_t *d_of_row, int32_t *s_of_row, int32_t *reps_pos, int32_t *reps_len, int32_t *seqrow,
-                      int64_t *occ_off, int64_t *summary, void *stream) {
+                      const int32_t *work_rows, int n_work_rows, uint8_t *ucodes, uint64_t *hashes, int32_t *ulen,
+                      int32_t *rep_u, int32_t *rep_g, int32_t *d_of_row, int32_t *s_of_row, int32_t *reps_pos,
+                      int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, void *stream) {
   if (n_views <= 0) return 0;
+  LAUNCH(k_ungap_hash, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, ucodes, hashes, ulen);
   LAUNCH(k_ungap_dedupe, n_views, BLOCK_VIEW, stream, arena, views, rowidx, kmer_size, ucodes, hashes, ulen, rep_u, rep_g,
          d_of_row, s_of_row, reps_pos, reps_len, seqrow, occ_off, summary);
   return check_launch("k_ungap_dedupe");

@@ -163,6 +163,16 @@ class BatchEngine:
         work[:, 2] = chunk * rows_per_chunk
         return work, rows_per_chunk
 
+    @staticmethod
+    def _row_chunk_work(tab: np.ndarray, chunk: int = 256) -> np.ndarray:
+        """{view, row chunk} pairs covering every row of every view (kernels that walk rows of big views in parallel)."""
+        cnt = (tab[:, 5] + chunk - 1) // chunk
+        total = int(cnt.sum())
+        w = np.empty((total, 2), np.int32)
+        w[:, 0] = np.repeat(np.arange(tab.shape[0]), cnt)
+        w[:, 1] = np.arange(total) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        return w
+
     # ------------------------------------------------------------------------------------------------ main entry
     def load(self, msas: List[MSA]):
         """Ingest: encode + lay out + upload the batch; afterwards the alignments are resident in HBM."""
@@ -227,9 +237,11 @@ class BatchEngine:
             d_mask = be.upload(given_mask.astype(np.uint32))
         d_maxrun, d_stack, d_ivflag = be.zeros(4 * total_cols), be.empty(16 * total_cols), be.zeros(8 * total_cols)
         d_iv, d_niv, d_status = be.empty(12 * total_cols), be.empty(4 * n), be.empty(4 * n)
+        wr = self._row_chunk_work(tab)
+        d_wr = be.upload(wr)
         be.call("mprg_partition", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), n, be.ptr(d_mask), L,
-                be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv), be.ptr(d_status),
-                be.stream, work=cells)
+                be.ptr(d_wr), len(wr), be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv),
+                be.ptr(d_status), be.stream, work=cells)
         self.counters["launches"] += 2
         mask = be.download(d_mask, np.uint32, total_cols)
         n_iv = be.download(d_niv, np.int32, n)
@@ -310,7 +322,7 @@ class BatchEngine:
         self.counters["launches"] += 2
         return be.download(d_further, np.int32, nA).astype(bool)
 
-    def _dedupe(self, d_sub, d_rowidx, n_views: int, tot_rows: int, tot_u: int, work: float = 0.0):
+    def _dedupe(self, d_sub, d_rowidx, n_views: int, tot_rows: int, tot_u: int, work: float = 0.0, sub=None):
         """mprg_ungap_dedupe over the views of `d_sub`; returns the device buffers by name."""
         be = self.be
         R = max(tot_rows, 1)
@@ -318,11 +330,13 @@ class BatchEngine:
                  rep_g=be.empty(4 * R), d_of_row=be.empty(4 * R), s_of_row=be.empty(4 * R), reps_pos=be.empty(4 * R),
                  reps_len=be.empty(4 * R), seqrow=be.empty(4 * R), occ_off=be.empty(8 * (R + n_views)),
                  summary=be.empty(64 * max(n_views, 1)))
+        wr = self._row_chunk_work(sub)
+        d_wr = be.upload(wr)
         be.call("mprg_ungap_dedupe", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), n_views, self.L,
-                be.ptr(b["ucodes"]), be.ptr(b["hash"]), be.ptr(b["ulen"]), be.ptr(b["rep_u"]), be.ptr(b["rep_g"]),
+                be.ptr(d_wr), len(wr), be.ptr(b["ucodes"]), be.ptr(b["hash"]), be.ptr(b["ulen"]), be.ptr(b["rep_u"]), be.ptr(b["rep_g"]),
                 be.ptr(b["d_of_row"]), be.ptr(b["s_of_row"]), be.ptr(b["reps_pos"]), be.ptr(b["reps_len"]),
                 be.ptr(b["seqrow"]), be.ptr(b["occ_off"]), be.ptr(b["summary"]), be.stream, work=work)
-        self.counters["launches"] += 1
+        self.counters["launches"] += 2
         return b
 
     # ------------------------------------------------------------------------------------------------ clustering
@@ -339,7 +353,7 @@ class BatchEngine:
         sub[:, 8] = np.cumsum(sub[:, 7]) - sub[:, 7]
         tot_rows, tot_u, tot_cols = int(sub[:, 5].sum()), int(usize.sum()), int(sub[:, 7].sum())
         d_sub = be.upload(sub)
-        dd = self._dedupe(d_sub, d_rowidx, len(sel), tot_rows, tot_u, work=2.0 * float((sub[:, 5] * sub[:, 7]).sum()))
+        dd = self._dedupe(d_sub, d_rowidx, len(sel), tot_rows, tot_u, work=2.0 * float((sub[:, 5] * sub[:, 7]).sum()), sub=sub)
         d_ucodes, d_ulen = dd["ucodes"], dd["ulen"]
         ulen = be.download(dd["ulen"], np.int32, tot_rows)
         rep_u = be.download(dd["rep_u"], np.int32, tot_rows)
@@ -722,7 +736,7 @@ def _bm_row_groups(self: BatchEngine, alignment: MSA):
     S = int(tab[0, 5])
     tab[0, 10] = 0
     d_sub = be.upload(tab)
-    dd = eng._dedupe(d_sub, d_rowidx, 1, S, int(tab[0, 7]) * ((S + 15) // 16 * 16))
+    dd = eng._dedupe(d_sub, d_rowidx, 1, S, int(tab[0, 7]) * ((S + 15) // 16 * 16), sub=tab)
     ru, rg = be.download(dd["rep_u"], np.int32, S), be.download(dd["rep_g"], np.int32, S)
     ulen = be.download(dd["ulen"], np.int32, S)
     ar = np.arange(S)
@@ -740,7 +754,7 @@ def _bm_cluster(self: BatchEngine, alignment: MSA, kmer_size: int):
     sub = tab.copy()
     sub[0, 10] = 0
     d_sub = be.upload(sub)
-    dd = eng._dedupe(d_sub, d_rowidx, 1, S, int(sub[0, 7]) * ((S + 15) // 16 * 16))
+    dd = eng._dedupe(d_sub, d_rowidx, 1, S, int(sub[0, 7]) * ((S + 15) // 16 * 16), sub=sub)
     d_ucodes, d_ulen = dd["ucodes"], dd["ulen"]
     ul, ru = be.download(dd["ulen"], np.int32, S), be.download(dd["rep_u"], np.int32, S)
     is_rep = ru == np.arange(S)

@@ -138,9 +138,11 @@ class ForestEngine(BatchEngine):
                 work.shape[0], rpc, be.ptr(d_mask), be.stream, work=cells)
         d_maxrun, d_stack, d_ivflag = be.zeros(4 * total_cols), be.empty(16 * total_cols), be.zeros(8 * total_cols)
         d_iv, d_niv, d_status = be.empty(12 * total_cols), be.empty(4 * n), be.empty(4 * n)
+        wr = self._row_chunk_work(tab)
+        d_wr = be.upload(wr)
         be.call("mprg_partition", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), n, be.ptr(d_mask), L,
-                be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv), be.ptr(d_status),
-                be.stream, work=cells)
+                be.ptr(d_wr), len(wr), be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv),
+                be.ptr(d_status), be.stream, work=cells)
         self.counters["launches"] += 2
         mask = be.download(d_mask, np.uint32, total_cols)
         n_iv = be.download(d_niv, np.int32, n).astype(np.int64)
@@ -216,7 +218,7 @@ class ForestEngine(BatchEngine):
         sub[:, 8] = _excl_cumsum(sub[:, 7])
         tot_rows, tot_u, tot_cols = int(S.sum()), int(usize.sum()), int(sub[:, 7].sum())
         d_sub, d_rowidx = be.upload(sub), self.d_pool
-        dd = self._dedupe(d_sub, d_rowidx, nsel, tot_rows, tot_u, work=2.0 * float((S * sub[:, 7]).sum()))
+        dd = self._dedupe(d_sub, d_rowidx, nsel, tot_rows, tot_u, work=2.0 * float((S * sub[:, 7]).sum()), sub=sub)
         sm = be.download(dd["summary"], np.int64, 8 * nsel).reshape(nsel, 8)
         n_uu, n_ug, Dq, Tq, sumlen, nshort = (sm[:, i] for i in range(6))
         # every selected view can end as a leaf whose alleles are its distinct rows (recursion_tree.py:272-274): the
