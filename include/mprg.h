@@ -106,18 +106,24 @@ int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int
  * (cluster_sequences.py:262-266; arithmetic restated from scikit-learn, see oracle/kmeans_oracle.c) with
  * n_init restarts.  Three launches:
  *   mprg_kmeans_prepare : per problem, centre X (prob[WS_OFF] workspace), row norms, tolerance.   (once per problem)
- *   mprg_kmeans_restarts: per (problem, restart): k-means++ from `uniforms` + Elkan iterations.
- *   mprg_kmeans_select  : per problem: best restart by the reference's rule, then predict().
- * uniforms_host: n_init * (1 + (k-1)*(2+int(ln k))) doubles of numpy RandomState(2).random_sample (host pointer,
- * copied by the call).  labels int32 at prob[LABEL_OFF]; km_status int32[n_probs]; km_info double[8*n_probs]
- * = {inertia, n_iter of the best restart, best restart, n distinct labels, total Elkan iterations, -, -, -}.
- * Workspace size per problem (doubles): mprg_kmeans_workspace_doubles(D, V, k_max, n_init). */
-int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_init);
+ *   mprg_kmeans_restarts: per fit = (problem, k): its n_init restarts side by side: k-means++ + Elkan iterations.
+ *   mprg_kmeans_select  : per fit: best restart by the reference's rule, then predict().
+ * A fit is 5 int32 (kinfo): {row of `prob`, k, first restart slot of the fit in the problem's workspace, offset (in
+ * doubles) of this k's uniforms in `uniforms_dev`, offset added to prob[LABEL_OFF] for the fit's labels}; several k of
+ * one problem can be fitted in one launch (they use disjoint restart slots), which the host uses to run the
+ * reference's k = 2,3,4,... loop a few k at a time.
+ * uniforms of one k: n_init * (1 + (k-1)*(2+int(ln k))) doubles of numpy RandomState(2).random_sample.
+ * labels int32; km_status int32[n_fits] (MPRG_KM_*); km_info double[8*n_fits] = {inertia, n_iter of the best restart,
+ * best restart, n distinct labels, total Elkan iterations, -, -, -}.
+ * Workspace size per problem (doubles): mprg_kmeans_workspace_doubles(D, V, k_max, restart slots). */
+int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_restart_slots);
 int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, void *stream);
-int mprg_kmeans_restarts(const int64_t *prob, int n_probs, int k, int n_init, const double *uniforms_dev,
+int mprg_kmeans_restarts(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
                          double *ws, int32_t *km_status, void *stream);
-int mprg_kmeans_select(const int64_t *prob, int n_probs, int k, int n_init, const double *xcounts, double *ws,
-                       int32_t *labels, int32_t *km_status, double *km_info, void *stream);
+int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *xcounts,
+                       double *ws, int32_t *labels, double *km_info, void *stream);
+/* labels of accepted fits -> the problems' assignment (read by mprg_split_children) */
+int mprg_commit_labels(const int64_t *prob, int n_probs, const int32_t *labels, int32_t *assign, void *stream);
 /* fills out[n] with numpy.random.RandomState(seed).random_sample(n) (host memory; MT19937) */
 void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
 

@@ -28,8 +28,9 @@ SIGNATURES = {
     "mprg_kmer_counts": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7),
     "mprg_kmeans_workspace_doubles": (c_int64, [c_int64, c_int64, c_int, c_int]),
     "mprg_kmeans_prepare": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    "mprg_kmeans_restarts": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "mprg_kmeans_select": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
+    "mprg_kmeans_restarts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mprg_kmeans_select": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 5),
+    "mprg_commit_labels": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int] + [c_void_p] * 3),
     "mprg_split_children": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 7),
     "mprg_leaf_jobs": (c_int, [c_void_p, c_int64] + [c_void_p] * 6),
@@ -130,7 +131,7 @@ class HipBackend(_Base):
         return buf[:nbytes].cpu().numpy().view(dtype)
 
     def ptr(self, buf) -> int:
-        return buf.data_ptr()
+        return buf.addr if hasattr(buf, "addr") else buf.data_ptr()
 
     def grown(self, buf, used_bytes: int, new_bytes: int):
         """A larger buffer holding the first used_bytes of buf (device-to-device copy)."""

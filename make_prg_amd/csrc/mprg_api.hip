@@ -107,9 +107,9 @@ int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int
   return check_launch("k_kmer_counts");
 }
 
-int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_init) {
+int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_restart_slots) {
   if (k_max > KM_KMAX) return -1;
-  return km_common_doubles_host(D, V) + (int64_t)n_init * km_restart_doubles_host(D, V);
+  return km_common_doubles_host(D, V) + (int64_t)n_restart_slots * km_restart_doubles_host(D, V);
 }
 
 int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, void *stream) {
@@ -118,22 +118,26 @@ int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts,
   return check_launch("k_kmeans_prepare");
 }
 
-int mprg_kmeans_restarts(const int64_t *prob, int n_probs, int k, int n_init, const double *uniforms_dev,
+int mprg_kmeans_restarts(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
                          double *ws, int32_t *km_status, void *stream) {
-  if (n_probs <= 0) return 0;
-  if (k < 2 || k > KM_KMAX) return fail("k must be in 2..10");
-  const int n_trials = 2 + (int)log((double)k);
+  if (n_fits <= 0) return 0;
   if (n_init > KM_RMAX) return fail("n_init must be <= 16");
-  LAUNCH(k_kmeans_restart, n_probs, env_threads("MPRG_KM_THREADS", 256), stream, prob, k, n_init, n_trials, uniforms_dev, ws, km_status);
+  LAUNCH(k_kmeans_restart, n_fits, env_threads("MPRG_KM_THREADS", 256), stream, prob, kinfo, n_init, uniforms_dev, ws,
+         km_status);
   return check_launch("k_kmeans_restart");
 }
 
-int mprg_kmeans_select(const int64_t *prob, int n_probs, int k, int n_init, const double *xcounts, double *ws,
-                       int32_t *labels, int32_t *km_status, double *km_info, void *stream) {
-  (void)km_status;
-  if (n_probs <= 0) return 0;
-  LAUNCH(k_kmeans_select, n_probs, 256, stream, prob, k, n_init, xcounts, ws, labels, km_info);
+int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *xcounts,
+                       double *ws, int32_t *labels, double *km_info, void *stream) {
+  if (n_fits <= 0) return 0;
+  LAUNCH(k_kmeans_select, n_fits, 256, stream, prob, kinfo, n_init, xcounts, ws, labels, km_info);
   return check_launch("k_kmeans_select");
+}
+
+int mprg_commit_labels(const int64_t *prob, int n_probs, const int32_t *labels, int32_t *assign, void *stream) {
+  if (n_probs <= 0) return 0;
+  LAUNCH(k_commit_labels, n_probs, 64, stream, prob, labels, assign);
+  return check_launch("k_commit_labels");
 }
 
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,

@@ -396,12 +396,25 @@ class BatchEngine:
                 new_nodes.extend(self._finish_cluster_node(nodes, p))
         return new_nodes
 
-    def _uniforms(self, k: int):
-        if k not in self._uniform_cache:
-            n_trials = 2 + int(np.log(k))
-            u = self.be.random_sample(2, N_INIT * (1 + (k - 1) * n_trials))
-            self._uniform_cache[k] = self.be.upload(u)
-        return self._uniform_cache[k]
+    def _uniforms_all(self):
+        """Device buffer with numpy RandomState(2).random_sample streams of every k = 2..10, and each k's offset."""
+        if "all" not in self._uniform_cache:
+            parts, offs, o = [], {}, 0
+            for k in range(2, MAX_CLUSTERS + 1):
+                n = N_INIT * (1 + (k - 1) * (2 + int(np.log(k))))
+                parts.append(self.be.random_sample(2, n))
+                offs[k] = o
+                o += n
+            self._uniform_cache["all"] = (self.be.upload(np.concatenate(parts)), offs)
+        return self._uniform_cache["all"]
+
+    def _kinfo(self, n_rows: int, k: int, restart_base: int = 0, label_base: int = 0) -> np.ndarray:
+        """Fit descriptors {problem row, k, restart slot base, uniform offset, label base} for rows 0..n_rows-1."""
+        _, offs = self._uniforms_all()
+        ki = np.empty((n_rows, 5), np.int32)
+        ki[:, 0] = np.arange(n_rows)
+        ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = k, restart_base, offs[k], label_base
+        return ki
 
     def _run_kmeans_problems(self, nodes, probs, sub, d_sub, d_rowidx, d_ucodes, d_ulen, tot_rows, tot_cols, d_dor):
         be, K = self.be, self.L
@@ -473,10 +486,11 @@ class BatchEngine:
             nA = len(active)
             d_st = be.zeros(4 * nA)
             km_work = [0.0]
-            be.call("mprg_kmeans_restarts", be.ptr(d_sp), nA, k, N_INIT, be.ptr(self._uniforms(k)), be.ptr(d_ws),
-                    be.ptr(d_st), be.stream)
-            be.call("mprg_kmeans_select", be.ptr(d_sp), nA, k, N_INIT, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_labels),
-                    be.ptr(d_st), be.ptr(d_info), be.stream)
+            d_ki = be.upload(self._kinfo(nA, k))
+            be.call("mprg_kmeans_restarts", be.ptr(d_sp), be.ptr(d_ki), nA, N_INIT, be.ptr(self._uniforms_all()[0]),
+                    be.ptr(d_ws), be.ptr(d_st), be.stream)
+            be.call("mprg_kmeans_select", be.ptr(d_sp), be.ptr(d_ki), nA, N_INIT, be.ptr(d_x), be.ptr(d_ws),
+                    be.ptr(d_labels), be.ptr(d_info), be.stream)
             self.counters["launches"] += 2
             st = be.download(d_st, np.int32, nA)
             info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)

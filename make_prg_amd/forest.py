@@ -60,8 +60,16 @@ class Growable:
         return {f: (np.concatenate(c) if c else np.zeros(0, self.fields[f])) for f, c in self.chunks.items()}
 
 
+class _Offset:
+    """A device buffer viewed from a byte offset (only its address is used)."""
+
+    def __init__(self, be, buf, nbytes):
+        self.addr = be.ptr(buf) + int(nbytes)
+
+
 class ForestEngine(BatchEngine):
     """load() as BatchEngine; run_forest() builds every tree of the batch; assemble_prgs() emits the PRG strings."""
+    k_slots = 3
 
     # ------------------------------------------------------------------------------------------------ device row pool
     def _pool_reserve(self, extra_rows: int):
@@ -266,49 +274,105 @@ class ForestEngine(BatchEngine):
         be.call("mprg_kmer_dictionary", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
                 be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), be.stream)
         V = be.download(d_V, np.int32, P).astype(np.int64)
-        wsz = 2 * D * V + 2 * V + D + 8 + N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)   # mprg_kmeans_workspace_doubles
+        NS = self.k_slots                                      # k values fitted per round (speculation depth)
+        wsz = 2 * D * V + 2 * V + D + 8 + NS * N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)   # mprg_kmeans_workspace_doubles
         ptab[:, 7], ptab[:, 8], ptab[:, 9], ptab[:, 10] = V, _excl_cumsum(D * V), _excl_cumsum(wsz), so
         lo = int(D.sum())
         d_ptab = be.upload(ptab)
         d_x, d_ws = be.zeros(8 * int((D * V).sum())), be.empty(8 * int(wsz.sum()))
-        d_labels, d_assign, d_info = be.empty(4 * lo), be.zeros(4 * lo), be.empty(64 * P)
+        d_labels, d_assign = be.empty(4 * lo * NS), be.zeros(4 * lo)
         be.call("mprg_kmer_counts", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
                 be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_x), be.stream)
         be.call("mprg_kmeans_prepare", be.ptr(d_ptab), P, be.ptr(d_x), be.ptr(d_ws), be.stream)
         self.counters["launches"] += 3
-        # cluster_sequences.py:256-274, all problems of the level in lock-step (k is the same for every active one)
+        d_uni, uoff = self._uniforms_all()
+        uoff_arr = np.zeros(MAX_CLUSTERS + 1, np.int64)
+        for k_, o_ in uoff.items():
+            uoff_arr[k_] = o_
+
+        # cluster_sequences.py:256-274 for all problems of the level, NS values of k per round: the fits of k, k+1, ...
+        # of a problem are independent (every KMeans() starts from a fresh RandomState(2)), so they run in ONE launch;
+        # the host then replays the reference's sequential decisions over the results and discards fits made in vain.
         num_clusters = np.ones(P, np.int64)
         active = np.arange(P)
-        k = 1
-        while len(active):
-            k += 1
-            num_clusters[active] += 1
-            active = active[(num_clusters[active] <= MAX_CLUSTERS) & (num_clusters[active] != D[active])]
-            if not len(active):
-                break
-            nA = len(active)
-            d_sp, d_st = be.upload(ptab[active]), be.zeros(4 * nA)
-            be.call("mprg_kmeans_restarts", be.ptr(d_sp), nA, k, N_INIT, be.ptr(self._uniforms(k)), be.ptr(d_ws),
-                    be.ptr(d_st), be.stream)
-            be.call("mprg_kmeans_select", be.ptr(d_sp), nA, k, N_INIT, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_labels),
-                    be.ptr(d_st), be.ptr(d_info), be.stream)
-            self.counters["launches"] += 2
-            st = be.download(d_st, np.int32, nA)
-            info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
-            if (st & 2).any():
-                raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
-                                "is not restated on the device; refusing to continue with a possibly different result")
-            kb = float((8.0 * D[active] * V[active] * (info[:, 4] + N_INIT)).sum())
-            self.counters["fits"] += nA
-            self.counters["kmeans_bytes"] += kb
-            if be.profile is not None and be.profile.get("mprg_kmeans_restarts"):
+        kmax = np.minimum(MAX_CLUSTERS, D - 1)                  # k == D stops the loop before a fit (:260-261)
+        k_base = 2
+        while len(active) and k_base <= MAX_CLUSTERS:
+            ks = [k for k in range(k_base, min(k_base + NS, MAX_CLUSTERS + 1))]
+            ent_prob, ent_k, ent_slot = [], [], []
+            for s_, k in enumerate(ks):
+                el = active[kmax[active] >= k]
+                ent_prob.append(el); ent_k.append(np.full(len(el), k)); ent_slot.append(np.full(len(el), s_))
+            ent_prob, ent_k, ent_slot = np.concatenate(ent_prob), np.concatenate(ent_k), np.concatenate(ent_slot)
+            nF = len(ent_prob)
+            if nF:
+                ki = np.empty((nF, 5), np.int32)
+                ki[:, 0], ki[:, 1], ki[:, 2] = ent_prob, ent_k, ent_slot * N_INIT
+                ki[:, 3], ki[:, 4] = uoff_arr[ent_k], ent_slot * lo
+                d_ki, d_st, d_info = be.upload(ki), be.zeros(4 * nF), be.empty(64 * nF)
+                be.call("mprg_kmeans_restarts", be.ptr(d_ptab), be.ptr(d_ki), nF, N_INIT, be.ptr(d_uni), be.ptr(d_ws),
+                        be.ptr(d_st), be.stream)
+                be.call("mprg_kmeans_select", be.ptr(d_ptab), be.ptr(d_ki), nF, N_INIT, be.ptr(d_x), be.ptr(d_ws),
+                        be.ptr(d_labels), be.ptr(d_info), be.stream)
+                self.counters["launches"] += 2
+                # cluster_further of every fit, slot by slot (labels of slot s live at d_labels + s*lo)
+                further = np.zeros(nF, bool)
+                for s_, k in enumerate(ks):
+                    m = np.nonzero(ent_slot == s_)[0]
+                    if len(m):
+                        further[m] = self._cluster_further(d_sub, d_rowidx, sub, ptab[ent_prob[m]], k, dd["d_of_row"],
+                                                           _Offset(be, d_labels, 4 * lo * s_), None, d_scratch, d_further)
+                st = be.download(d_st, np.int32, nF)
+                info = be.download(d_info, np.float64, 8 * nF).reshape(nF, 8)
+                if (st & 2).any():
+                    raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
+                                    "is not restated on the device; refusing to continue with a possibly different result")
+            # replay the reference's loop over this round's k values
+            done = np.zeros(P, bool)
+            acc_slot = np.full(P, -1, np.int64)
+            ent_of = {}                                          # (slot) -> entry index per problem
+            for s_, k in enumerate(ks):
+                cand = np.zeros(P, bool)
+                cand[active] = True
+                cand &= ~done
+                num_clusters[cand] += 1
+                over = cand & ((num_clusters > MAX_CLUSTERS) | (num_clusters == D))
+                done |= over
+                cand &= ~over
+                if not cand.any():
+                    continue
+                m = np.nonzero(ent_slot == s_)[0]
+                e_of_p = np.full(P, -1, np.int64)
+                e_of_p[ent_prob[m]] = m
+                ce = e_of_p[cand]                                # every candidate has a fit in this slot
+                pidx = np.nonzero(cand)[0]
+                used = ce >= 0
+                pidx, ce = pidx[used], ce[used]
+                kb = float((8.0 * D[pidx] * V[pidx] * (info[ce, 4] + N_INIT)).sum())
+                self.counters["fits"] += len(pidx)
+                self.counters["kmeans_bytes"] += kb
+                bad = info[ce, 3].astype(np.int64) < k           # cluster_sequences.py:267-273: revert and stop
+                num_clusters[pidx[bad]] -= 1
+                done[pidx[bad]] = True
+                good_p, good_e = pidx[~bad], ce[~bad]
+                acc_slot[good_p] = s_
+                done[good_p[~further[good_e]]] = True
+            # commit the labels of each problem's last accepted fit of this round
+            for s_ in range(len(ks)):
+                cp = np.nonzero(acc_slot == s_)[0]
+                if len(cp):
+                    d_cp = be.upload(ptab[cp])
+                    be.call("mprg_commit_labels", be.ptr(d_cp), len(cp), be.ptr(_Offset(be, d_labels, 4 * lo * s_)),
+                            be.ptr(d_assign), be.stream)
+                    self.counters["launches"] += 1
+            if be.profile is not None and be.profile.get("mprg_kmeans_restarts") and nF:
                 a0, a1, _ = be.profile["mprg_kmeans_restarts"][-1]
-                be.profile["mprg_kmeans_restarts"][-1] = (a0, a1, kb)
-            good = info[:, 3].astype(np.int64) >= k
-            num_clusters[active[~good]] -= 1                     # cluster_sequences.py:267-273: revert and stop
-            active = active[good]
-            if len(active):
-                active = active[check(ptab[active], k, d_labels, d_assign)]
+                be.profile["mprg_kmeans_restarts"][-1] = (a0, a1, float((8.0 * D[ent_prob] * V[ent_prob] * (info[:, 4] + N_INIT)).sum()))
+            active = active[~done[active]]
+            k_base += NS
+        # the reference leaves num_clusters at 11 when the loop ends by exceeding MAX_CLUSTERS (:258-259)
+        still = active
+        num_clusters[still] = np.where(num_clusters[still] >= MAX_CLUSTERS, MAX_CLUSTERS + 1, num_clusters[still])
 
         # ---- MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
         splits = np.nonzero((num_clusters != 1) & (num_clusters != D))[0]

@@ -28,9 +28,12 @@ def run_kmeans_fits(be, fits, n_init=10):
         d_lab, d_st, d_info = be.empty(4 * lo), be.zeros(4 * P), be.empty(64 * P)
         n_trials = 2 + int(np.log(k))
         d_u = be.upload(be.random_sample(2, n_init * (1 + (k - 1) * n_trials)))
+        ki = np.zeros((P, 5), np.int32)
+        ki[:, 0], ki[:, 1] = np.arange(P), k
+        d_ki = be.upload(ki)
         be.call("mprg_kmeans_prepare", be.ptr(d_p), P, be.ptr(d_x), be.ptr(d_ws), be.stream)
-        be.call("mprg_kmeans_restarts", be.ptr(d_p), P, k, n_init, be.ptr(d_u), be.ptr(d_ws), be.ptr(d_st), be.stream)
-        be.call("mprg_kmeans_select", be.ptr(d_p), P, k, n_init, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_lab), be.ptr(d_st),
+        be.call("mprg_kmeans_restarts", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_u), be.ptr(d_ws), be.ptr(d_st), be.stream)
+        be.call("mprg_kmeans_select", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_lab),
                 be.ptr(d_info), be.stream)
         labels = be.download(d_lab, np.int32, lo)
         info = be.download(d_info, np.float64, 8 * P).reshape(P, 8)
