@@ -131,7 +131,7 @@ class HipBackend(_Base):
         return buf[:nbytes].cpu().numpy().view(dtype)
 
     def ptr(self, buf) -> int:
-        return buf.addr if hasattr(buf, "addr") else buf.data_ptr()
+        return buf.mprg_addr if hasattr(buf, "mprg_addr") else buf.data_ptr()
 
     def grown(self, buf, used_bytes: int, new_bytes: int):
         """A larger buffer holding the first used_bytes of buf (device-to-device copy)."""

@@ -64,7 +64,7 @@ class _Offset:
     """A device buffer viewed from a byte offset (only its address is used)."""
 
     def __init__(self, be, buf, nbytes):
-        self.addr = be.ptr(buf) + int(nbytes)
+        self.mprg_addr = be.ptr(buf) + int(nbytes)
 
 
 class ForestEngine(BatchEngine):

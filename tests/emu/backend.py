@@ -52,7 +52,7 @@ class EmuBackend(_Base):
         return buf[:nbytes].copy().view(dtype)
 
     def ptr(self, buf):
-        return buf.addr if hasattr(buf, "addr") else buf.ctypes.data
+        return buf.mprg_addr if hasattr(buf, "mprg_addr") else buf.ctypes.data
 
     def grown(self, buf, used_bytes, new_bytes):
         new = np.full(int(new_bytes), 0xA5, np.uint8)
