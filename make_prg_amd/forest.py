@@ -69,7 +69,7 @@ class _Offset:
 
 class ForestEngine(BatchEngine):
     """load() as BatchEngine; run_forest() builds every tree of the batch; assemble_prgs() emits the PRG strings."""
-    k_slots = 3
+    k_slots = 1          # k values fitted per round; >1 fits k, k+1, .. speculatively in one launch (measured: no gain)
 
     # ------------------------------------------------------------------------------------------------ device row pool
     def _pool_reserve(self, extra_rows: int):
