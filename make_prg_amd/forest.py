@@ -297,7 +297,40 @@ class ForestEngine(BatchEngine):
         active = np.arange(P)
         kmax = np.minimum(MAX_CLUSTERS, D - 1)                  # k == D stops the loop before a fit (:260-261)
         k_base = 2
-        while len(active) and k_base <= MAX_CLUSTERS:
+        k = 1
+        while NS == 1 and len(active):                          # one k per round: the reference's loop as it stands
+            k += 1
+            num_clusters[active] += 1
+            active = active[(num_clusters[active] <= MAX_CLUSTERS) & (num_clusters[active] != D[active])]
+            if not len(active):
+                break
+            nA = len(active)
+            ki = np.empty((nA, 5), np.int32)
+            ki[:, 0], ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = active, k, 0, uoff_arr[k], 0
+            d_ki, d_st, d_info = be.upload(ki), be.zeros(4 * nA), be.empty(64 * nA)
+            be.call("mprg_kmeans_restarts", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_uni), be.ptr(d_ws),
+                    be.ptr(d_st), be.stream)
+            be.call("mprg_kmeans_select", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_x), be.ptr(d_ws),
+                    be.ptr(d_labels), be.ptr(d_info), be.stream)
+            self.counters["launches"] += 2
+            st = be.download(d_st, np.int32, nA)
+            info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
+            if (st & 2).any():
+                raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
+                                "is not restated on the device; refusing to continue with a possibly different result")
+            kb = float((8.0 * D[active] * V[active] * (info[:, 4] + N_INIT)).sum())
+            self.counters["fits"] += nA
+            self.counters["kmeans_bytes"] += kb
+            if be.profile is not None and be.profile.get("mprg_kmeans_restarts"):
+                a0, a1, _ = be.profile["mprg_kmeans_restarts"][-1]
+                be.profile["mprg_kmeans_restarts"][-1] = (a0, a1, kb)
+            good = info[:, 3].astype(np.int64) >= k
+            num_clusters[active[~good]] -= 1                     # cluster_sequences.py:267-273: revert and stop
+            active = active[good]
+            if len(active):                                      # also commits the accepted labels
+                active = active[self._cluster_further(d_sub, d_rowidx, sub, ptab[active], k, dd["d_of_row"], d_labels,
+                                                      d_assign, d_scratch, d_further)]
+        while NS > 1 and len(active) and k_base <= MAX_CLUSTERS:
             ks = [k for k in range(k_base, min(k_base + NS, MAX_CLUSTERS + 1))]
             ent_prob, ent_k, ent_slot = [], [], []
             for s_, k in enumerate(ks):
@@ -371,8 +404,9 @@ class ForestEngine(BatchEngine):
             active = active[~done[active]]
             k_base += NS
         # the reference leaves num_clusters at 11 when the loop ends by exceeding MAX_CLUSTERS (:258-259)
-        still = active
-        num_clusters[still] = np.where(num_clusters[still] >= MAX_CLUSTERS, MAX_CLUSTERS + 1, num_clusters[still])
+        if NS > 1:
+            still = active
+            num_clusters[still] = np.where(num_clusters[still] >= MAX_CLUSTERS, MAX_CLUSTERS + 1, num_clusters[still])
 
         # ---- MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
         splits = np.nonzero((num_clusters != 1) & (num_clusters != D))[0]
