@@ -18,6 +18,7 @@
 #include <algorithm>
 #define MPRG_DEV static inline
 #define KERNEL(name, ...) static void name(int mprg_bid, int mprg_nthreads, __VA_ARGS__)
+#define KERNEL_OCC(name, waves, ...) KERNEL(name, __VA_ARGS__)
 #define LAUNCH(name, nblocks, nthreads, stream, ...)                          \
   do { for (int b_ = 0; b_ < (int)(nblocks); ++b_) name(b_, (int)(nthreads), __VA_ARGS__); } while (0)
 #define BLOCK_ID mprg_bid
@@ -42,6 +43,7 @@ template <class T> MPRG_DEV T emu_atomic_cas(T *p, T c, T v) { T o = *p; if (o =
 #include <hip/hip_runtime.h>
 #define MPRG_DEV __device__ __forceinline__
 #define KERNEL(name, ...) __global__ void name(__VA_ARGS__)
+#define KERNEL_OCC(name, waves, ...) __attribute__((amdgpu_waves_per_eu(waves, 8))) __global__ void name(__VA_ARGS__)
 #define LAUNCH(name, nblocks, nthreads, stream, ...) \
   hipLaunchKernelGGL(name, dim3((unsigned)(nblocks)), dim3((unsigned)(nthreads)), 0, (hipStream_t)(stream), __VA_ARGS__)
 #define BLOCK_ID ((int)blockIdx.x)
