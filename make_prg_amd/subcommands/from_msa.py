@@ -84,24 +84,55 @@ def shard_files(files: List[Path], rank: int, world: int) -> List[Path]:
     return mine
 
 
+def _load_one(args):
+    path, fmt = args
+    try:
+        return load_alignment_file(path, fmt)
+    except ValueError as err:
+        return err
+
+
+def load_many(files: List[Path], alignment_format: str, procs: int = 1) -> list:
+    """Parse + upper-case + N-replace every file (utils/io_utils.py:17-49), with `procs` worker processes.
+    Must run before the GPU is initialised when procs > 1 (the workers are forked)."""
+    jobs = [(f, alignment_format) for f in files]
+    if procs > 1 and len(files) >= 32:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(procs) as pool:
+            return pool.map(_load_one, jobs, chunksize=16)
+    return [_load_one(j) for j in jobs]
+
+
+BATCH = int(os.environ.get("MPRG_BATCH", "4096"))          # alignments per resident batch
+
+
 def build_shard(files: List[Path], options, backend=None) -> Dict[str, dict]:
-    """All loci of this rank: {locus: {prg, bin, gfa, pickle}}; loci skipped by the curation policy are absent."""
+    """All loci of this rank: {locus: {prg, bin, gfa, pickle}}; loci skipped by the curation policy are absent.
+    Ingest runs in `-t` worker processes (the reference's -t starts that many per-alignment workers); the build runs
+    in resident batches of MPRG_BATCH alignments on this rank's GPU."""
+    loaded = load_many(files, options.alignment_format, max(1, int(getattr(options, "threads", 1) or 1)))
+    out: Dict[str, dict] = {}
+    for lo in range(0, len(files), BATCH):
+        chunk_files = files[lo:lo + BATCH]
+        msas, loci = [], []
+        for f, m in zip(chunk_files, loaded[lo:lo + BATCH]):
+            locus = remove_known_input_extensions(f.name)
+            if isinstance(m, ValueError):
+                if "No records found in handle" in str(m.args[0]):
+                    raise EmptyMSAError(f"No records found in MSA of locus {locus}")
+                raise m
+            msas.append(m)
+            loci.append(locus)
+        _build_batch(msas, loci, options, backend, out)
+    return out
+
+
+def _build_batch(msas, loci, options, backend, out: Dict[str, dict]):
     from ..device import get_backend
     from ..prg_builder import PrgBuilder
     from ..recursion_tree import materialise
-    msas, loci = [], []
-    for f in files:
-        locus = remove_known_input_extensions(f.name)
-        try:
-            msas.append(load_alignment_file(f, options.alignment_format))
-        except ValueError as err:
-            if "No records found in handle" in str(err.args[0]):
-                raise EmptyMSAError(f"No records found in MSA of locus {locus}")
-            raise
-        loci.append(locus)
-    out: Dict[str, dict] = {}
     if not msas:
-        return out
+        return
     be = backend or get_backend()
     ot = options.output_type
 
@@ -149,7 +180,6 @@ def build_shard(files: List[Path], options, backend=None) -> Dict[str, dict]:
                 continue
             prg, _, _ = build_prg(eng2, res)
             emit(loci[i], msas[i], prg, lambda b, res=res, i=i: materialise(eng2, res, msas[i], b, None))
-    return out
 
 
 def write_final_files(all_loci: Dict[str, dict], output_type, output_prefix: str):
