@@ -26,15 +26,14 @@ def _expected(cfg, seeds):
         return pool.map(_oracle, [(cfg, s) for s in seeds], chunksize=4)
 
 
-# computed at import time of the first test that needs it, BEFORE any HIP call in this process (fork safety)
-_CACHE = {}
+CASES = [("B", 0, 1000), ("C", 5000, 5128)]
 
 
-def expected(cfg, seeds):
-    key = (cfg, seeds[0], seeds[-1])
-    if key not in _CACHE:
-        _CACHE[key] = _expected(cfg, seeds)
-    return _CACHE[key]
+@pytest.fixture(scope="module")
+def oracle_results():
+    """All expectations first: the worker processes are forked before this process makes its first HIP call
+    (this file sorts before the other GPU test files)."""
+    return {(cfg, lo, hi): _expected(cfg, list(range(lo, hi))) for cfg, lo, hi in CASES}
 
 
 def run_gpu(cfg, seeds):
@@ -58,10 +57,10 @@ def check_markers(prg):
     assert all(u for u in units)
 
 
-@pytest.mark.parametrize("cfg,lo,hi", [("B", 0, 1000), ("C", 5000, 5128)])
-def test_full_config_against_oracle(cfg, lo, hi):
+@pytest.mark.parametrize("cfg,lo,hi", CASES)
+def test_full_config_against_oracle(oracle_results, cfg, lo, hi):
     seeds = list(range(lo, hi))
-    want = expected(cfg, seeds)          # forks: must precede GPU initialisation in this process
+    want = oracle_results[(cfg, lo, hi)]
     prgs, n_nodes = run_gpu(cfg, seeds)
     bad = [s for s, p, (w, _) in zip(seeds, prgs, want) if p != w]
     assert not bad, f"{len(bad)} of {len(seeds)} loci differ from the oracle, first seeds {bad[:5]}"
