@@ -111,7 +111,7 @@ def main():
     def one(i):
         with bes[i].on_stream():
             engs[i].run_forest()                      # recursion forest: kernels + array-at-a-time host control
-            prgs = engs[i].assemble_prgs()            # PRG strings of every locus of the sub-batch
+            prgs = engs[i].assemble_prgs(as_bytes=True)   # PRG text (ASCII) of every locus of the sub-batch
             bes[i].synchronize()
         return sum(p is not None for p in prgs), sum(len(p) for p in prgs if p)
 

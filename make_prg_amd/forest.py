@@ -507,7 +507,7 @@ def _special_leaf_alleles(self: "ForestEngine", leaves: np.ndarray) -> Dict[int,
     return out
 
 
-def assemble_prgs(self: ForestEngine, want_index: bool = False):
+def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool = False):
     """PRG string of every alignment of the batch (None for loci dropped by the curation policy).
     Host (per-node arrays only): preorder ranks and site numbers by prefix sums over the node table, text lengths
     bottom-up, text offsets top-down, cluster-node site markers.  Device: every leaf's alleles and its own markers
@@ -629,7 +629,9 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False):
         be.call("mprg_emit_alleles", be.ptr(self.d_arena), be.ptr(d_jobs), n_jobs, be.ptr(d_out), be.stream,
                 work=float((nseq[dl] * t["ncols"][dl]).sum() + achars[dl].sum()))
         self.counters["launches"] += 1
-    buf = be.download(d_out, np.uint8, total_chars).copy()
+    buf = be.download(d_out, np.uint8, total_chars)
+    if not buf.flags.writeable:
+        buf = buf.copy()
     # ---- host: cluster-node markers, host-expanded leaves --------------------------------------------------------------------
     cn = np.nonzero(clus)[0]
     _write_markers(buf, start[cn], site[cn])
@@ -656,9 +658,14 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False):
                 buf[pos:pos + len(mtxt)] = np.frombuffer(mtxt, np.uint8)
                 pos += len(mtxt)
     out: List[Optional[str]] = [None] * M
-    whole = buf.tobytes()
-    for i in np.nonzero(~self.failed)[0]:
-        out[i] = whole[msa_base[i]:msa_base[i] + msa_len[i]].decode()
+    if as_bytes:          # zero-copy views into the batch buffer (ASCII)
+        mv = memoryview(buf)
+        for i in np.nonzero(~self.failed)[0]:
+            out[i] = mv[msa_base[i]:msa_base[i] + msa_len[i]]
+    else:
+        whole = buf.tobytes()
+        for i in np.nonzero(~self.failed)[0]:
+            out[i] = whole[msa_base[i]:msa_base[i] + msa_len[i]].decode()
     self.node_id = pre
     self.site_count = n_sites
     if want_index:      # prg_index: every allele of every leaf (recursion_tree.py:276-300)
