@@ -165,7 +165,8 @@ def main():
         # committed ratio traffic/algorithmic of the profiled run is applied to this run's algorithmic bytes per launch
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01b", "pmc_summary.json")))
+            import glob
+            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")))[-1]))
             ratio = pm["kernels"][{"mprg_kmeans_restarts": "k_kmeans_restart"}.get(name, name.replace("mprg_", "k_"))]["traffic_over_algorithmic"]
             traffic = round(ratio * d["bytes"] / max(launches, 1), 1)
         except Exception:
