@@ -61,10 +61,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=2048, help="alignments per GPU per step")
+    ap.add_argument("--batch", type=int, default=8192, help="alignments per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=3, help="host threads / HIP streams per GPU (each owns a sub-batch)")
+    ap.add_argument("--streams", type=int, default=4, help="host threads / HIP streams per GPU (each owns a sub-batch)")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes for input generation (0 = auto; use 1 under rocprofv3)")
     args = ap.parse_args()
 

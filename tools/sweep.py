@@ -18,6 +18,17 @@ variants = [
     ("s2b4k", {"MPRG_KM_THREADS": "128"}, ["--streams", "2", "--batch", "4096"]),
     ("s1b4k", {"MPRG_KM_THREADS": "128"}, ["--streams", "1", "--batch", "4096"]),
     ("s2k64", {"MPRG_KM_THREADS": "64"}, ["--streams", "2"]),
+    ("t2", {}, ["--streams", "2"]),
+    ("t3", {}, ["--streams", "3"]),
+    ("t4", {}, ["--streams", "4"]),
+    ("t6", {}, ["--streams", "6"]),
+    ("t4b4k", {}, ["--streams", "4", "--batch", "4096"]),
+    ("t4b8k", {}, ["--streams", "4", "--batch", "8192"]),
+    ("t6b8k", {}, ["--streams", "6", "--batch", "8192"]),
+    ("t8b8k", {}, ["--streams", "8", "--batch", "8192"]),
+    ("t8b16k", {}, ["--streams", "8", "--batch", "16384"]),
+    ("t3b8k", {}, ["--streams", "3", "--batch", "8192"]),
+    ("t3b1k", {}, ["--streams", "3", "--batch", "1024"]),
     ("s1k256", {"MPRG_KM_THREADS": "256"}, ["--streams", "1"]),
     ("s1k512", {"MPRG_KM_THREADS": "512"}, ["--streams", "1"]),
     ("s1k1024", {"MPRG_KM_THREADS": "1024"}, ["--streams", "1"]),
