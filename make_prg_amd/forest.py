@@ -275,7 +275,7 @@ class ForestEngine(BatchEngine):
                 be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), be.stream)
         V = be.download(d_V, np.int32, P).astype(np.int64)
         NS = self.k_slots                                      # k values fitted per round (speculation depth)
-        wsz = 2 * D * V + 2 * V + D + 8 + NS * N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)   # mprg_kmeans_workspace_doubles
+        wsz = 2 * D * V + 2 * V + D + 8 + 3 * D * D + NS * N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)   # mprg_kmeans_workspace_doubles
         ptab[:, 7], ptab[:, 8], ptab[:, 9], ptab[:, 10] = V, _excl_cumsum(D * V), _excl_cumsum(wsz), so
         lo = int(D.sum())
         d_ptab = be.upload(ptab)
@@ -294,7 +294,7 @@ class ForestEngine(BatchEngine):
         # of a problem are independent (every KMeans() starts from a fresh RandomState(2)), so they run in ONE launch;
         # the host then replays the reference's sequential decisions over the results and discards fits made in vain.
         num_clusters = np.ones(P, np.int64)
-        active = np.arange(P)
+        active = np.argsort(-(D * V), kind="stable")            # biggest fits first: the grid's tail is its largest problem
         kmax = np.minimum(MAX_CLUSTERS, D - 1)                  # k == D stops the loop before a fit (:260-261)
         k_base = 2
         k = 1
