@@ -56,6 +56,67 @@ def cpu_baseline(n_sample, procs):
     return n_sample / dt, dt
 
 
+def _worker(conn, device, seeds, n_streams, profile_mode):
+    """One host worker process: owns `n_streams` engines (HIP streams, one host thread each) on GPU `device` and a share
+    of the rank's alignments.  The reference's own parallelism is a process pool over MSAs (from_msa `-t`); here the
+    processes feed one GPU so that the array-at-a-time host control of several sub-batches overlaps."""
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        from make_prg_amd.backend import HipBackend
+        from make_prg_amd.forest import ForestEngine
+        msas = [_gen(s) for s in seeds]
+        n_streams = max(1, min(n_streams, len(msas)))
+        bes = [HipBackend(device, own_stream=True) for _ in range(n_streams)]
+        engs = [ForestEngine(b, max_nesting=5, min_match_length=7) for b in bes]
+        t_ing = time.perf_counter()
+        for i, (e, b) in enumerate(zip(engs, bes)):      # ingest: encode + upload; inputs are now resident in HBM
+            with b.on_stream():
+                e.load(msas[i::n_streams])
+            b.synchronize()
+        t_ing = time.perf_counter() - t_ing
+        pool = ThreadPoolExecutor(n_streams)
+
+        def one(i):
+            with bes[i].on_stream():
+                engs[i].run_forest()                          # recursion forest: kernels + array-at-a-time host control
+                prgs = engs[i].assemble_prgs(as_bytes=True)   # PRG text (ASCII) of every locus of the sub-batch
+                bes[i].synchronize()
+            return sum(p is not None for p in prgs), sum(len(p) for p in prgs if p)
+
+        conn.send(("ready", t_ing))
+        while True:
+            cmd, arg = conn.recv()
+            if cmd == "steps":
+                n_ok = chars = 0
+                for _ in range(arg):
+                    res = list(pool.map(one, range(n_streams)))
+                    n_ok, chars = sum(r[0] for r in res), sum(r[1] for r in res)
+                conn.send(("done", (n_ok, chars)))
+            elif cmd == "reset":
+                for b in bes:
+                    b.profile = {} if profile_mode != "none" else None
+                    b.profile_only = {"mprg_kmeans_restarts"} if profile_mode == "dominant" else None
+                for e in engs:
+                    for key in e.counters:
+                        e.counters[key] = 0 if key != "arena_bytes" else e.counters[key]
+                conn.send(("done", None))
+            elif cmd == "report":
+                prof = {}
+                for b in bes:
+                    for k_, v_ in b.profile_summary().items():
+                        a = prof.setdefault(k_, dict(calls=0, ms=0.0, bytes=0.0))
+                        a["calls"] += v_["calls"]; a["ms"] += v_["ms"]; a["bytes"] += v_["bytes"]
+                    b.profile = None
+                counters = {k_: sum(e.counters.get(k_, 0) for e in engs) for k_ in engs[0].counters}
+                counters["levels"] = max(e.counters["levels"] for e in engs)
+                conn.send(("done", (prof, counters)))
+            else:
+                return
+    except BaseException as err:        # the parent must hear about it: there is no silent fallback
+        import traceback
+        conn.send(("error", f"{type(err).__name__}: {err}\n{traceback.format_exc()}"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,17 +125,22 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="alignments per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, help="host threads / HIP streams per GPU (each owns a sub-batch)")
-    ap.add_argument("--gen-procs", type=int, default=0, help="processes for input generation (0 = auto; use 1 under rocprofv3)")
+    ap.add_argument("--workers", type=int, default=8, help="host worker processes per GPU (each owns a sub-batch)")
+    ap.add_argument("--streams", type=int, default=1, help="host threads / HIP streams per worker process")
+    ap.add_argument("--profile", choices=("dominant", "all", "none"), default="all",
+                    help="HIP-event timing inside the timed region: the dominant kernel's entry point only, every entry "
+                         "point (adds event traffic to every launch), or none")
+    ap.add_argument("--gen-procs", type=int, default=0, help="(unused; the workers generate their own alignments)")
     args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
+                     "--master-port P bench.py --gpus N ...")
     ncpu = os.cpu_count() or 1
-
-    # CPU baseline first (rank 0, single-GPU runs only), before the GPU is initialised: it forks worker processes
     cpu = None
+    # CPU baseline first, before this process or its workers touch the GPU (fork-safe, and nothing else is running)
     if world == 1 and not args.no_cpu_baseline:
         n = args.cpu_sample or max(ncpu * 6, 48)
         v, dt = cpu_baseline(n, ncpu)
@@ -82,72 +148,71 @@ def main():
                    sample=f"{n} config-C alignments (seeds 1000000..), oracle/ (Python + C KMeans restatement of the "
                           f"reference path), {ncpu} worker processes, one alignment per task, {dt:.1f}s wall")
 
-    procs_gen = args.gen_procs or max(1, min(ncpu // max(world, 1), 16))
+    # host workers are forked BEFORE this process initialises the GPU (a forked HIP context is unusable)
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    W = max(1, min(args.workers, args.batch))
     seeds = [rank * 100_000 + i for i in range(args.batch)]
-    msas = make_batch(seeds, procs_gen)
+    conns, procs = [], []
+    for w in range(W):
+        a, b = ctx.Pipe()
+        pr = ctx.Process(target=_worker, args=(b, local_rank, seeds[w::W], args.streams, args.profile), daemon=True)
+        pr.start()
+        conns.append(a); procs.append(pr)
+
+    def gather(expect="done"):
+        out = []
+        for c in conns:
+            tag, val = c.recv()
+            if tag == "error":
+                sys.stderr.write(val)
+                for pr in procs:
+                    pr.terminate()
+                sys.exit(1)
+            assert tag == expect, (tag, expect)
+            out.append(val)
+        return out
+
+    def command(cmd, arg=None):
+        for c in conns:
+            c.send((cmd, arg))
+        return gather()
+
+    t_ing = max(gather("ready"))
 
     import torch
     import torch.distributed as dist
-    from make_prg_amd.backend import HipBackend
-    from make_prg_amd.forest import ForestEngine
-
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from concurrent.futures import ThreadPoolExecutor
-    n_streams = max(1, min(args.streams, args.batch))
-    bes = [HipBackend(local_rank, own_stream=n_streams > 1) for _ in range(n_streams)]
-    be = bes[0]
-    engs = [ForestEngine(b, max_nesting=5, min_match_length=7) for b in bes]
-    eng = engs[0]
-    shards = [msas[i::n_streams] for i in range(n_streams)]
-    t_ing = time.perf_counter()
-    for e, b, sh in zip(engs, bes, shards):          # ingest: encode + upload; inputs are now resident in HBM
-        with b.on_stream():
-            e.load(sh)
-    t_ing = time.perf_counter() - t_ing
-    pool = ThreadPoolExecutor(n_streams)
-
-    def one(i):
-        with bes[i].on_stream():
-            engs[i].run_forest()                      # recursion forest: kernels + array-at-a-time host control
-            prgs = engs[i].assemble_prgs(as_bytes=True)   # PRG text (ASCII) of every locus of the sub-batch
-            bes[i].synchronize()
-        return sum(p is not None for p in prgs), sum(len(p) for p in prgs if p)
-
-    def step():
-        res = list(pool.map(one, range(n_streams)))
-        return sum(r[0] for r in res), sum(r[1] for r in res)
+    device = torch.device("cuda", local_rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(device)     # the workers synchronise their own streams before they answer "done"
 
-    for _ in range(args.warmup):
-        step()
-    for b in bes:
-        b.profile = {}
-    for e in engs:
-        for key in e.counters:
-            e.counters[key] = 0 if key != "arena_bytes" else e.counters[key]
+    command("steps", args.warmup)
+    command("reset")
     barrier()
     t0 = time.perf_counter()
-    n_ok = 0
-    for _ in range(args.steps):
-        n_ok, chars = step()
+    res = command("steps", args.steps)       # every worker runs its K steps back to back; no collective on the data path
     barrier()
     dt = time.perf_counter() - t0
+    n_ok = sum(r[0] for r in res)
+    reports = command("report")
+    for c in conns:
+        c.send(("quit", None))
     prof = {}
-    for b in bes:
-        for k_, v_ in b.profile_summary().items():
+    for pr_, _ in reports:
+        for k_, v_ in pr_.items():
             a = prof.setdefault(k_, dict(calls=0, ms=0.0, bytes=0.0))
             a["calls"] += v_["calls"]; a["ms"] += v_["ms"]; a["bytes"] += v_["bytes"]
-        b.profile = None
-    counters = {k_: sum(e.counters.get(k_, 0) for e in engs) for k_ in engs[0].counters}
-    counters["levels"] = max(e.counters["levels"] for e in engs)
+    counters = {k_: sum(c_[k_] for _, c_ in reports) for k_ in reports[0][1]}
+    counters["levels"] = max(c_["levels"] for _, c_ in reports)
+    n_streams = args.streams
 
-    t = torch.tensor([dt], dtype=torch.float64, device=be.device)
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
@@ -156,6 +221,8 @@ def main():
 
     if rank == 0:
         dev_ms = sum(v["ms"] for v in prof.values())
+        if not prof:
+            prof = {"mprg_kmeans_restarts": dict(calls=0, ms=0.0, bytes=0.0)}
         dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
         name, d = dom
         launches = d["calls"]
@@ -185,7 +252,8 @@ def main():
             "vs_baseline": None, "dtype": "u8 (+f64 KMeans)", "data": "synthetic",
             "config": {"workload": "C: 30k-gene pan-genome shape (S~N(100,20) in [20,300] rows x 1000-3000 cols, "
                                    "SURVEY.md §8d generator), -N 5 -L 7; one step = one resident batch per GPU",
-                       "batch_per_gpu": args.batch, "parallelism": f"shard{world}", "host_threads_streams_per_gpu": n_streams,
+                       "batch_per_gpu": args.batch, "parallelism": f"shard{world}", "host_worker_processes_per_gpu": W, "streams_per_worker": n_streams,
+                       "event_timing": args.profile,
                        "step_includes": "recursion forest on device + host control + PRG string emission",
                        "ingest_s_excluded": round(t_ing, 3), "device_ms_per_step": round(dev_ms / args.steps, 3),
                        "levels": counters["levels"] / args.steps, "launches_per_step": counters["launches"] / args.steps,
@@ -197,6 +265,8 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+    for pr in procs:
+        pr.join(timeout=30)
     if world > 1:
         dist.destroy_process_group()
 

@@ -59,11 +59,16 @@ int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t 
  * in:  mask (from mprg_column_masks), min_match_length.
  * scratch: maxrun uint32[total_cols] (zeroed), stack int32[4*total_cols], ivflag int32[total_cols*2] (zeroed)
  * out: iv int32[3*total_cols] as {start, stop, type} triples at 3*col_off, n_iv int32[n_views],
- *      status int32[n_views]. */
+ *      status int32[n_views].
+ * optional (all three NULL or all three set): view_out int32[8*n_views] = {n_iv, status, type of the first interval,
+ *      flags (1: some column is not one plain base, i.e. the consensus has a '*' or a gap; 2: N or ambiguity codes
+ *      occur), first triple of this view in iv_packed, 0, 0, 0}; iv_packed int32[3*total_cols] = the triples of all
+ *      views back to back (a view's triples are contiguous; views in order of completion); iv_count int32[1]
+ *      (zeroed) = triples appended. */
 int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
                    const uint32_t *mask, int min_match_length, const int32_t *work_rows, int n_work_rows,
                    uint32_t *maxrun, int32_t *stack, int32_t *ivflag, int32_t *iv, int32_t *n_iv, int32_t *status,
-                   void *stream);
+                   int32_t *view_out, int32_t *iv_packed, int32_t *iv_count, void *stream);
 
 /* A9a/A13/A16 — from_msa/cluster_sequences.py:220-233 (ungap, group identical rows in first-appearance order),
  * utils/seq_utils.py:58-70 (unique gapped / ungapped counts).  Ungap + hash: one workgroup per (view, 256-row chunk)

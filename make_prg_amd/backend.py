@@ -22,7 +22,7 @@ SIGNATURES = {
     "mprg_last_error": (ctypes.c_char_p, []),
     "mprg_device_cus": (c_int, []),
     "mprg_column_masks": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p, c_void_p]),
-    "mprg_partition": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 7),
+    "mprg_partition": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 10),
     "mprg_ungap_dedupe": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p, c_int] + [c_void_p] * 13),
     "mprg_kmer_dictionary": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8),
     "mprg_kmer_counts": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7),
@@ -55,10 +55,11 @@ class _Base:
     """Shared call helper: every kernel entry point returns 0 or raises with the library's message."""
 
     profile = None   # set to a dict to collect per-entry-point device time (HIP events on the launch stream)
+    profile_only = None   # optional set of entry points to time (None: all of them)
 
     def call(self, name, *args, work: float = 0.0):
         """Enqueue one C-ABI entry point.  `work` = algorithmic bytes of this launch (roofline accounting)."""
-        ev = self._event_pair() if self.profile is not None else None
+        ev = self._event_pair() if self.profile is not None and (self.profile_only is None or name in self.profile_only) else None
         if ev:
             ev[0].record()
         rc = getattr(self.lib, name)(*args)

@@ -101,7 +101,7 @@ class ForestEngine(BatchEngine):
                           ncols=np.int64))
         self.T = T
         self.res_chunks: Dict[str, list] = {k: [] for k in ("kind", "first_child", "n_child", "lvl", "col_off", "leaf_mode",
-                                                            "reps_off", "nseq", "allele_chars", "node_level")}
+                                                            "reps_off", "nseq", "allele_chars", "node_level", "special")}
         ok = np.nonzero(~self.failed)[0]
         cur = dict(msa=ok, parent=np.full(len(ok), -1, np.int64), level=np.zeros(len(ok), np.int64),
                    rowlist=np.full(len(ok), -1, np.int64), col0=np.zeros(len(ok), np.int64), ncols=meta[ok, 5].copy())
@@ -146,22 +146,21 @@ class ForestEngine(BatchEngine):
                 work.shape[0], rpc, be.ptr(d_mask), be.stream, work=cells)
         d_maxrun, d_stack, d_ivflag = be.zeros(4 * total_cols), be.empty(16 * total_cols), be.zeros(8 * total_cols)
         d_iv, d_niv, d_status = be.empty(12 * total_cols), be.empty(4 * n), be.empty(4 * n)
+        d_vout, d_ivp, d_ivc = be.empty(32 * n), be.empty(12 * total_cols), be.zeros(4)
         wr = self._row_chunk_work(tab)
         d_wr = be.upload(wr)
         be.call("mprg_partition", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), n, be.ptr(d_mask), L,
                 be.ptr(d_wr), len(wr), be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv),
-                be.ptr(d_status), be.stream, work=cells)
+                be.ptr(d_status), be.ptr(d_vout), be.ptr(d_ivp), be.ptr(d_ivc), be.stream, work=cells)
         self.counters["launches"] += 2
-        mask = be.download(d_mask, np.uint32, total_cols)
-        n_iv = be.download(d_niv, np.int32, n).astype(np.int64)
-        status = be.download(d_status, np.int32, n)
-        iv = be.download(d_iv, np.int32, 3 * total_cols).reshape(-1, 3).astype(np.int64)
-
-        mm = mask & ~np.uint32(BIT_N)
-        single = (mm != 0) & ((mm & (mm - 1)) == 0) & ((mm & BITS_IUPAC) == 0) & (mm != BIT_GAP)
+        # the column masks and the per-column interval slots stay on the device: the host reads one record per view
+        # and the sum(n_iv) interval triples
+        vout = be.download(d_vout, np.int32, 8 * n).reshape(n, 8)
+        n_iv, status, first_type = vout[:, 0].astype(np.int64), vout[:, 1], vout[:, 2]
+        has_star, special, iv_off = (vout[:, 3] & 1) != 0, (vout[:, 3] & 2) != 0, vout[:, 4].astype(np.int64)
+        iv = be.download(d_ivp, np.int32, 3 * int(n_iv.sum())).reshape(-1, 3).astype(np.int64)
         lvl = len(self.levels)
-        self.levels.append(dict(allgap=(mask == BIT_GAP), special=(mask & np.uint32(BITS_IUPAC | BIT_N)) != 0,
-                                idx=cur["idx"]))
+        self.levels.append(dict(idx=cur["idx"]))
 
         if status.any():          # per-locus policy: the locus is dropped, the batch goes on
             for j in np.nonzero(status)[0]:
@@ -172,16 +171,14 @@ class ForestEngine(BatchEngine):
                                        if status[j] & 2 else PartitioningError("Failed interval partitioning"))
         alive = ~self.failed[cur["msa"]]
         col_off = tab[:, 8]
-        first_type = iv[np.minimum(col_off, max(total_cols - 1, 0)), 2] if total_cols else np.zeros(n, np.int64)
         is_leaf = alive & (n_iv == 1) & (first_type == 0)
         is_interval = alive & ~is_leaf & ((n_iv > 1) | (cur["parent"] < 0))
         is_cand = alive & ~is_leaf & ~is_interval
-        has_star = _seg_sum((~single).astype(np.int64), tab[:, 7]) > 0
 
         R = dict(kind=np.full(n, KIND_LEAF, np.int8), first_child=np.full(n, -1, np.int64), n_child=np.zeros(n, np.int64),
                  lvl=np.full(n, lvl, np.int64), col_off=col_off.copy(), leaf_mode=np.zeros(n, np.int8),
                  reps_off=np.full(n, -1, np.int64), nseq=np.ones(n, np.int64), allele_chars=cur["ncols"].copy(),
-                 node_level=cur["level"].copy())
+                 node_level=cur["level"].copy(), special=special)
         R["kind"][is_interval] = KIND_INTERVAL
         nxt = {k: [] for k in ("msa", "parent", "level", "rowlist", "col0", "ncols", "idx")}
 
@@ -197,7 +194,7 @@ class ForestEngine(BatchEngine):
         if is_interval.any():
             pj = np.nonzero(is_interval)[0]
             cnt = n_iv[pj]
-            src = np.repeat(col_off[pj], cnt) + _seg_arange(cnt)
+            src = np.repeat(iv_off[pj], cnt) + _seg_arange(cnt)
             par = np.repeat(pj, cnt)
             idx = add_children(par, cur["rowlist"][par], cur["col0"][par] + iv[src, 0], iv[src, 1] - iv[src, 0] + 1,
                                cur["level"][par])
@@ -452,11 +449,6 @@ class ForestEngine(BatchEngine):
             t[key] = out
         t["level"] = t.pop("node_level")
         self.tab = t
-        widths = np.asarray([len(lv["allgap"]) for lv in self.levels], dtype=np.int64)
-        offs = _excl_cumsum(widths) if len(widths) else np.zeros(0, np.int64)
-        cat = (lambda key, dt: np.concatenate([lv[key] for lv in self.levels]) if self.levels else np.zeros(0, dt))
-        self.allgap_all, self.special_all = cat("allgap", bool), cat("special", bool)
-        t["gcol_off"] = offs[t["lvl"]] + t["col_off"] if n else np.zeros(0, np.int64)
 
 
 # ======================================================================================================= PRG assembly
@@ -528,10 +520,8 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool =
     # leaves with ambiguity codes / N in their columns: host expansion
     host_leaf: Dict[int, List[str]] = {}
     l1 = np.nonzero(leaf_all & (t["leaf_mode"] == 1))[0]
-    if len(l1) and self.special_all.any():
-        spc = np.concatenate(([0], np.cumsum(self.special_all)))
-        g = t["gcol_off"][l1]
-        sp_leaves = l1[(spc[g + t["ncols"][l1]] - spc[g]) > 0]
+    if len(l1):
+        sp_leaves = l1[t["special"][l1]]                    # the view's masks held N / ambiguity codes (mprg_partition)
         sp_leaves = sp_leaves[~self.failed[msa[sp_leaves]]]
         if len(sp_leaves):
             host_leaf = _special_leaf_alleles(self, sp_leaves)
@@ -542,12 +532,21 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool =
     nseq[~valid] = 0
     is_leaf = leaf_all & valid
     # ---- preorder rank inside each tree ------------------------------------------------------------------------------
+    def add_children_to_parents(val):
+        """val[p] += sum of val over p's children, bottom-up (a level's nodes are one contiguous index range and the
+        children of a node are contiguous inside it, so the sums are differences of one running sum per level)."""
+        for lv in reversed(self.levels[1:]):
+            idx = lv["idx"]
+            if not len(idx):
+                continue
+            c = np.concatenate(([0], np.cumsum(val[idx])))
+            pp = parent[idx]
+            P = pp[idx == fch[pp]]
+            lo = fch[P] - idx[0]
+            val[P] += c[lo + nch[P]] - c[lo]
+
     size = np.ones(n, np.int64)
-    for lv in reversed(self.levels):
-        idx = lv["idx"]
-        p = parent[idx]
-        h = p >= 0
-        np.add.at(size, p[h], size[idx[h]])
+    add_children_to_parents(size)
     pre = np.zeros(n, np.int64)
     for lv in self.levels[1:]:
         idx = lv["idx"]
@@ -575,11 +574,7 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool =
     total[multi] += open_len[multi] * 2 + (nseq[multi] - 1) * mid_len[multi]
     clus = valid & (kind == KIND_CLUSTER)
     total[clus] = open_len[clus] * 2 + (nch[clus] - 1) * mid_len[clus]
-    for lv in reversed(self.levels):
-        idx = lv["idx"]
-        p = parent[idx]
-        h = (p >= 0) & valid[idx]
-        np.add.at(total, p[h], total[idx[h]])
+    add_children_to_parents(total)                         # nodes of dropped loci carry 0 throughout
     start = np.zeros(n, np.int64)
     roots = self.root_of[~self.failed & (self.root_of >= 0)]
     msa_len = np.zeros(M, np.int64)
@@ -696,9 +691,9 @@ def forest_tree_dump(self: ForestEngine, mi: int, ids: List[str]) -> list:
         ni = stack.pop()
         rl = int(t["rowlist"][ni])
         rows = np.arange(codes.shape[0]) if rl < 0 else pool[self.rl_off[rl]:self.rl_off[rl] + self.rl_len[rl]]
-        c0, w, g = int(t["col0"][ni]), int(t["ncols"][ni]), int(t["gcol_off"][ni])
-        keep = ~self.allgap_all[g:g + w]
-        block = decode(codes[rows, c0:c0 + w][:, keep])
+        c0, w = int(t["col0"][ni]), int(t["ncols"][ni])
+        block = codes[rows, c0:c0 + w]
+        block = decode(block[:, ~(block == CODE_GAP).all(axis=0)])      # all-gap columns are not stored (recursion_tree.py:45)
         kids = [int(t["first_child"][ni]) + j for j in range(int(t["n_child"][ni]))]
         par = int(t["parent"][ni])
         out.append(dict(id=int(self.node_id[ni]), kind=kinds[int(t["kind"][ni])], level=int(t["level"][ni]),

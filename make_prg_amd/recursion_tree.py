@@ -194,9 +194,10 @@ def materialise_forest(eng, mi: int, alignment: MSA, prg_builder) -> RecursiveTr
     def make(ni: int, parent) -> RecursiveTreeNode:
         rl = int(t["rowlist"][ni])
         rows = np.arange(data.shape[0]) if rl < 0 else pool[eng.rl_off[rl]:eng.rl_off[rl] + eng.rl_len[rl]]
-        c0, w, g = int(t["col0"][ni]), int(t["ncols"][ni]), int(t["gcol_off"][ni])
-        keep = ~eng.allgap_all[g:g + w]
-        stored = MSA(_data=data[rows, c0:c0 + w][:, keep], _ids=[alignment.ids[r] for r in rows],
+        c0, w = int(t["col0"][ni]), int(t["ncols"][ni])
+        block = data[rows, c0:c0 + w]
+        keep = ~(block == ord("-")).all(axis=0)              # remove_columns_full_of_gaps_from_MSA (recursion_tree.py:45)
+        stored = MSA(_data=block[:, keep], _ids=[alignment.ids[r] for r in rows],
                      _descs=[alignment.descriptions[r] for r in rows])
         level, kind = int(t["level"][ni]), int(t["kind"][ni])
         if kind == KIND_LEAF:

@@ -17,7 +17,7 @@ eng.load(msas)
 
 def step():
     eng.run_forest()
-    return eng.assemble_prgs()
+    return eng.assemble_prgs(as_bytes=True)
 
 
 step()
@@ -25,4 +25,4 @@ pr = cProfile.Profile()
 pr.enable()
 step()
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(32)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
