@@ -151,7 +151,7 @@ def main():
     # host workers are forked BEFORE this process initialises the GPU (a forked HIP context is unusable)
     import multiprocessing as mp
     ctx = mp.get_context("fork")
-    W = max(1, min(args.workers, args.batch))
+    W = max(0, min(args.workers, args.batch))
     seeds = [rank * 100_000 + i for i in range(args.batch)]
     conns, procs = [], []
     for w in range(W):
@@ -159,6 +159,12 @@ def main():
         pr = ctx.Process(target=_worker, args=(b, local_rank, seeds[w::W], args.streams, args.profile), daemon=True)
         pr.start()
         conns.append(a); procs.append(pr)
+    if W == 0:          # --workers 0: the same worker loop on a thread of this process (rocprofv3 runs: nothing forks)
+        import threading
+        a, b = ctx.Pipe()
+        th = threading.Thread(target=_worker, args=(b, local_rank, seeds, args.streams, args.profile), daemon=True)
+        th.start()
+        conns.append(a)
 
     def gather(expect="done"):
         out = []
@@ -168,7 +174,7 @@ def main():
                 sys.stderr.write(val)
                 for pr in procs:
                     pr.terminate()
-                sys.exit(1)
+                os._exit(1)
             assert tag == expect, (tag, expect)
             out.append(val)
         return out

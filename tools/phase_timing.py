@@ -1,0 +1,32 @@
+"""GPU-box helper: share of k_kmeans_restart's workgroup time per phase (diagnostic build -DKM_PHASE_TIMING,
+make_prg_amd/_lib/libmprg_hip_timing.so: shader-clock cycles of thread 0 between barriers, summed over all fits)."""
+import ctypes
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from bench import make_batch
+from make_prg_amd.backend import HipBackend
+import make_prg_amd.forest as F
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "make_prg_amd", "_lib", "libmprg_hip_timing.so")
+msas = make_batch(list(range(n)), 16)
+be = HipBackend(0, lib_path=lib)
+eng = F.ForestEngine(be, 5, 7)
+eng.load(msas)
+eng.run_forest()
+be.synchronize()
+out = (ctypes.c_ulonglong * 16)()
+be.lib.mprg_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
+be.lib.mprg_debug_phase_cycles(None, 1)
+eng.run_forest()
+be.synchronize()
+be.lib.mprg_debug_phase_cycles(out, 0)
+c = np.array(list(out), dtype=np.float64)
+names = ["k-means++ first centre", "k-means++ further centres", "centre-centre distances", "sample-centre distances",
+         "init bounds / E-step", "M-step sums", "cluster sizes / relocation", "average centres", "shift, bounds, stop test",
+         "inertia"]
+for nm, v in zip(names, c):
+    print(f"{100 * v / c.sum():6.1f} %  {nm}")
+print("fits", eng.counters["fits"], "cycles/fit", c.sum() / max(eng.counters["fits"], 1))
