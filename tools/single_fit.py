@@ -32,7 +32,11 @@ for i, c in enumerate(rows):
     for j, n in c.items():
         X[i, j] = n
 print("D", D, "V", V)
-be = HipBackend(0)
+import ctypes
+timing = os.environ.get("MPRG_TIMING_LIB")
+be = HipBackend(0, lib_path=timing) if timing else HipBackend(0)
+if timing:
+    be.lib.mprg_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
 be.profile = {}
 for rep in range(2):
     for k in range(2, 11):
@@ -40,5 +44,12 @@ for rep in range(2):
         res = run_kmeans_fits(be, [dict(k=k, shape=(D, V), counts_i16_hex=X.astype("<i2").tobytes().hex())])
         e0, e1, _ = be.profile["mprg_kmeans_restarts"][-1]
         p0, p1, _ = be.profile["mprg_kmeans_prepare"][-1]
+        if rep and timing:
+            out = (ctypes.c_ulonglong * 16)()
+            be.lib.mprg_debug_phase_cycles(out, 1)
+            c = np.array(list(out), dtype=np.float64)
+            print("   phase % :", " ".join(f"{100 * v / c.sum():.0f}" for v in c[:10]), " Mcycles", round(c.sum() / 1e6, 2))
+        elif timing:
+            be.lib.mprg_debug_phase_cycles(None, 1)
         if rep:
             print("k", k, "restart ms", round(e0.elapsed_time(e1), 3), "prepare ms", round(p0.elapsed_time(p1), 3), "n_iter(best)", res[0]["n_iter"])
