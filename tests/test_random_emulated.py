@@ -22,3 +22,46 @@ def test_forest_host(emu, N, L, seed, monkeypatch):
 def test_node_host(emu, N, L, seed, monkeypatch):
     monkeypatch.setattr(pc, "ENGINE", "nodes")
     pc.check_vs_oracle(emu, random_cases(seed, 80), N, L)
+
+
+def _wide_fasta(seed, S, C, p_mut, gaps=True):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 4, C)
+    out = []
+    for i in range(S):
+        y = base.copy()
+        m = rng.random(C) < p_mut
+        y[m] = rng.integers(0, 4, int(m.sum()))
+        txt = np.frombuffer(b"ACGT", np.uint8)[y].copy()
+        if gaps:
+            for st in np.nonzero(rng.random(C) < 0.003)[0]:
+                txt[st:st + int(rng.integers(1, 5))] = ord("-")
+        out.append(f">w{i}\n{txt.tobytes().decode()}\n")
+    return "".join(out)
+
+
+@pytest.mark.parametrize("N,L,S,C,p", [(2, 1, 5, 900, 0.02),       # n/(L-1) exceeds the LDS interval stacks: global stacks
+                                       (2, 2, 4, 1400, 0.05),
+                                       (1, 7, 3, 9000, 0.002)])    # wider than the LDS column bytes: masks read directly
+def test_wide_views_take_the_fallback_paths(emu, N, L, S, C, p, monkeypatch):
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    pc.check_vs_oracle(emu, [_wide_fasta(100 + C, S, C, p)], N, L)
+
+
+def test_tall_view_takes_the_unbucketed_majority_path(emu, monkeypatch):
+    """More rows than the LDS member lists of k_cluster_majority hold (CF_ROWS)."""
+    import numpy as np
+    rng = np.random.default_rng(77)
+    C = 48
+    clades = [rng.integers(0, 4, C) for _ in range(3)]
+    variants = []
+    for cl in clades:
+        for _ in range(4):
+            y = cl.copy()
+            y[rng.integers(0, C, 2)] = rng.integers(0, 4, 2)
+            variants.append(y)
+    rows = [variants[int(rng.integers(0, len(variants)))] for _ in range(1100)]
+    text = "".join(f">t{i}\n{np.frombuffer(b'ACGT', np.uint8)[r].tobytes().decode()}\n" for i, r in enumerate(rows))
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    pc.check_vs_oracle(emu, [text], 5, 7)
