@@ -19,21 +19,25 @@ SRC_DIR = os.path.join(ROOT, "make_prg_amd", "csrc")
 LIB = os.path.join(HERE, "_build", "libmprg_emu.so")
 
 
-def build_emu(force=False) -> str:
+def build_emu(force=False, defines=(), tag="") -> str:
+    """`defines`: extra -D switches of test-only variants (e.g. MPRG_TEST_WEAK_HASH: every row hash collides, so the
+    exact-comparison fallbacks run); `tag` names the variant's library."""
+    lib = LIB.replace(".so", f"{tag}.so")
     srcs = [os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR)] + [os.path.join(ROOT, "include", "mprg.h")]
     newest = max(os.path.getmtime(s) for s in srcs)
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    if force or not os.path.exists(lib) or os.path.getmtime(lib) < newest:
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
         subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-DMPRG_CPU_EMU", "-O2", "-ffp-contract=off", "-mfma",
-                               "-fPIC", "-shared", "-Wno-unused-function", os.path.join(SRC_DIR, "mprg_api.hip"), "-o", LIB])
-    return LIB
+                               "-fPIC", "-shared", "-Wno-unused-function"] + [f"-D{d}" for d in defines] +
+                              [os.path.join(SRC_DIR, "mprg_api.hip"), "-o", lib])
+    return lib
 
 
 class EmuBackend(_Base):
     name = "cpu-emulation(test-only)"
 
-    def __init__(self):
-        self.lib = bind(ctypes.CDLL(build_emu()))
+    def __init__(self, defines=(), tag=""):
+        self.lib = bind(ctypes.CDLL(build_emu(defines=defines, tag=tag)))
         self.stream = None
         self.n_cus = 1
 

@@ -65,3 +65,11 @@ def test_tall_view_takes_the_unbucketed_majority_path(emu, monkeypatch):
     text = "".join(f">t{i}\n{np.frombuffer(b'ACGT', np.uint8)[r].tobytes().decode()}\n" for i, r in enumerate(rows))
     monkeypatch.setattr(pc, "ENGINE", "forest")
     pc.check_vs_oracle(emu, [text], 5, 7)
+
+
+def test_row_grouping_is_exact_when_every_hash_collides(monkeypatch):
+    """Test-only build whose row hash only counts symbols: the nominee check refutes, the exact search decides."""
+    weak = EmuBackend(defines=("MPRG_TEST_WEAK_HASH",), tag="_weakhash")
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    pc.check_vs_oracle(weak, random_cases(31, 120), 5, 7)
+    pc.check_vs_oracle(weak, random_cases(32, 60), 3, 2)
