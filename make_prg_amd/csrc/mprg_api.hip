@@ -204,9 +204,9 @@ void mprg_random_sample_host(uint32_t seed, int n, double *out) {
 }
 
 #ifdef KM_PHASE_TIMING
-int mprg_debug_phase_cycles(unsigned long long *out16, int reset) {
-  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(km_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(km_phase_cycles), z, sizeof(z)) != hipSuccess) return -1; }
+int mprg_debug_phase_cycles(unsigned long long *out32, int reset) {
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(km_phase_cycles), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(km_phase_cycles), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
 #endif

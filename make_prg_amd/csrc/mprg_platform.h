@@ -99,3 +99,19 @@ MPRG_DEV int consensus_code(uint32_t mask) {
   while (!((m >> c) & 1u)) ++c;
   return c;
 }
+
+// ---- diagnostic build only (-DKM_PHASE_TIMING, tools/phase_timing.py): shader-clock cycles thread 0 of every workgroup
+// spends between marks, summed per mark id (0-15: k_kmeans_restart, 16-31: k_partition)
+#if defined(KM_PHASE_TIMING) && !defined(MPRG_CPU_EMU)
+__device__ unsigned long long km_phase_cycles[32];
+#define KM_T0() long long km_t0 = clock64()
+#define KM_TPARAM , long long &km_t0
+#define KM_TARG , km_t0
+#define KM_T(id) do { if (threadIdx.x == 0) { const long long now_ = clock64(); atomicAdd(&km_phase_cycles[id], (unsigned long long)(now_ - km_t0)); km_t0 = now_; } } while (0)
+#else
+#define KM_T0() ((void)0)
+#define KM_TPARAM
+#define KM_TARG
+#define KM_T(id) ((void)0)
+#endif
+

@@ -17,7 +17,7 @@ eng = F.ForestEngine(be, 5, 7)
 eng.load(msas)
 eng.run_forest()
 be.synchronize()
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 32)()
 be.lib.mprg_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
 be.lib.mprg_debug_phase_cycles(None, 1)
 eng.run_forest()
@@ -28,5 +28,8 @@ names = ["k-means++ first centre", "k-means++ further centres", "centre-centre d
          "init bounds / E-step", "M-step sums", "cluster sizes / relocation", "average centres", "shift, bounds, stop test",
          "inertia"]
 for nm, v in zip(names, c):
-    print(f"{100 * v / c.sum():6.1f} %  {nm}")
-print("fits", eng.counters["fits"], "cycles/fit", c.sum() / max(eng.counters["fits"], 1))
+    print(f"{100 * v / c[:16].sum():6.1f} %  {nm}")
+pn = ["column flags", "serial scan", "pass A (N rows)", "pass B (row comparison)", "merge", "copy-out"]
+for nm, v in zip(pn, c[16:]):
+    print(f"{100 * v / max(c[16:].sum(), 1):6.1f} %  k_partition: {nm}   ({v / 1e6:.1f} Mcycles)")
+print("fits", eng.counters["fits"], "cycles/fit", c[:16].sum() / max(eng.counters["fits"], 1))
