@@ -17,6 +17,7 @@
 #include <string.h>
 #include <algorithm>
 #define MPRG_DEV static inline
+#define MPRG_DEVM inline
 #define KERNEL(name, ...) static void name(int mprg_bid, int mprg_nthreads, __VA_ARGS__)
 #define KERNEL_OCC(name, waves, ...) KERNEL(name, __VA_ARGS__)
 #define LAUNCH(name, nblocks, nthreads, stream, ...)                          \
@@ -42,6 +43,7 @@ template <class T> MPRG_DEV T emu_atomic_cas(T *p, T c, T v) { T o = *p; if (o =
 #else
 #include <hip/hip_runtime.h>
 #define MPRG_DEV __device__ __forceinline__
+#define MPRG_DEVM __device__ __forceinline__
 #define KERNEL(name, ...) __global__ void name(__VA_ARGS__)
 #define KERNEL_OCC(name, waves, ...) __attribute__((amdgpu_waves_per_eu(waves, 8))) __global__ void name(__VA_ARGS__)
 #define LAUNCH(name, nblocks, nthreads, stream, ...) \

@@ -32,3 +32,19 @@ def check(backend, fits):
 
 def test_relocation_matches_oracle():
     check(EmuBackend(), degenerate_fits(7, 60))
+
+
+def test_fits_with_many_samples():
+    """Count matrices with more samples than the pan-genome shapes of the golden fits (several 8-wide operand blocks)."""
+    rng = np.random.default_rng(3)
+    fits = []
+    for D, V, k in ((70, 9, 3), (90, 5, 2), (130, 7, 10), (66, 30, 6)):
+        centres = rng.integers(0, 6, (4, V))
+        M = (centres[rng.integers(0, 4, D)] + rng.integers(0, 2, (D, V))).astype(np.float64)
+        lab, dbg = orc.kmeans_fit_predict(M, k, want_debug=True)
+        fits.append(dict(shape=[D, V], counts_i16_hex=M.astype("<i2").tobytes().hex(), k=k, labels=lab.tolist(),
+                         inertia=float(dbg["inertia"]).hex(), n_iter=dbg["n_iter"]))
+    got = run_kmeans_fits(EmuBackend(), fits)
+    for g, f in zip(got, fits):
+        assert not g["status"] & 2
+        assert g["labels"] == f["labels"] and g["inertia_hex"] == f["inertia"] and g["n_iter"] == f["n_iter"]
