@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_PKG, "_lib", "libmprg_hip.so")
+HIP_LIB_PATH = os.environ.get("MPRG_HIP_LIB") or os.path.join(_PKG, "_lib", "libmprg_hip.so")   # MPRG_HIP_LIB: diagnostic builds
 
 c_void_p, c_int, c_int64, c_uint32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint32
 

@@ -32,7 +32,7 @@ static int check_launch(const char *name) {
 static int env_threads(const char *name, int dflt) {
   const char *e = getenv(name);
   const int v = e ? atoi(e) : dflt;
-  return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : dflt;
+  return (v >= 64 && v <= 256 && v % 64 == 0) ? v : dflt;
 }
 
 extern "C" {
