@@ -21,13 +21,14 @@ def main(argv=None):
                               "Default: %(default)s")
         par.add_argument("-F", "--force", action="store_true", default=False, help="Force overwrite previous output")
         par.add_argument("-t", "--threads", action="store", type=int, default=1,
-                         help="Accepted for compatibility; parallelism is one process per GPU. Default: %(default)d")
+                         help="Host worker processes per GPU (each builds a part of the rank's alignments on the rank's "
+                              "device); 0: one per CPU. Default: %(default)d")
         par.add_argument("-v", "--verbose", action="count", default=0, help="Increase output verbosity")
         par.add_argument("--log", help="Path to write log to. Default is stderr")
     args = parser.parse_args(argv)
     if hasattr(args, "func"):
         level = [logging.INFO, logging.DEBUG, logging.DEBUG][min(args.verbose, 2)]
-        logging.basicConfig(level=level, filename=args.log, stream=None if args.log else sys.stderr)
+        logging.basicConfig(level=level, **({"filename": args.log} if args.log else {"stream": sys.stderr}))
         if args.threads == 0:
             args.threads = os.cpu_count()
         args.func(args)

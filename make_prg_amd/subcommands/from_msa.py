@@ -182,6 +182,18 @@ def _build_batch(msas, loci, options, backend, out: Dict[str, dict]):
             emit(loci[i], msas[i], prg, lambda b, res=res, i=i: materialise(eng2, res, msas[i], b, None))
 
 
+def _build_part(job):
+    """One host worker process of `-t`: its share of the rank's files, built on the rank's GPU."""
+    files, options = job
+    options.threads = 1
+    return build_shard(files, options)
+
+
+def split_for_workers(files: List[Path], n: int) -> List[List[Path]]:
+    """Size-balanced split of a rank's files over its host worker processes (same greedy rule as shard_files)."""
+    return [p for p in (shard_files(files, w, n) for w in range(n)) if p]
+
+
 def write_final_files(all_loci: Dict[str, dict], output_type, output_prefix: str):
     """reference utils/input_output_files.py:73-162."""
     single = len(all_loci) == 1
@@ -202,6 +214,24 @@ def write_final_files(all_loci: Dict[str, dict], output_type, output_prefix: str
 
 def run(cl_options, backend=None):
     options = cl_options
+    # `-t N`: the reference starts N per-alignment worker processes; here N host worker processes share the rank's GPU,
+    # each building its part of the shard in resident batches (the array-at-a-time host control of one batch overlaps
+    # the kernels of the others).  They are forked before this process touches the GPU (a forked HIP context is
+    # unusable); with an explicit backend (tests) everything runs in-process.
+    n_workers = max(1, int(getattr(options, "threads", 1) or 1)) if backend is None else 1
+    pool = None
+    if n_workers > 1:
+        import multiprocessing as mp
+        pool = mp.get_context("fork").Pool(n_workers)
+    try:
+        return _run(options, backend, pool, n_workers)
+    finally:
+        if pool is not None:
+            pool.close()
+            pool.join()
+
+
+def _run(options, backend, pool, n_workers):
     rank, world, dist = _dist()
     input_files = get_all_input_files(options.input, options.suffix)
     if len(input_files) == 0:
@@ -210,7 +240,12 @@ def run(cl_options, backend=None):
         raise RuntimeError("One or more output files already exists, aborting run...")
     Path(options.output_prefix).parent.mkdir(parents=True, exist_ok=True)
     mine = shard_files(input_files, rank, world) if world > 1 else input_files
-    local = build_shard(mine, options, backend)
+    if pool is not None and len(mine) >= 2 * n_workers:
+        local = {}
+        for part in pool.map(_build_part, [(p, options) for p in split_for_workers(mine, n_workers)]):
+            local.update(part)
+    else:
+        local = build_shard(mine, options, backend)
     if dist is not None:
         gathered = [None] * world if rank == 0 else None
         dist.gather_object(local, gathered, dst=0)          # the single exchange of the job

@@ -82,3 +82,35 @@ def test_single_alignment_and_skip_policy(tmp_path, golden_integration):
     (empty / "e.fa").write_text("")
     with pytest.raises(from_msa.EmptyMSAError):
         from_msa.run(options(empty, tmp_path / "o3" / "z"))
+
+
+def test_host_worker_processes_give_the_same_files(tmp_path, golden_integration):
+    """`-t 2`: two forked host workers share the device (here: inherit the emulation backend), each building a part."""
+    from make_prg_amd import device
+    device.set_backend(EmuBackend())
+    case = next(c for c in golden_integration["cases"] if c["case"] == "several")
+    d = write_case(tmp_path, case)
+    assert len(case["loci"]) >= 4
+    outs = []
+    for t in (1, 2):
+        prefix = tmp_path / f"out{t}" / "several"
+        o = options(d, prefix)
+        o.threads = t
+        from_msa.run(o)
+        outs.append({p.name: p.read_bytes() for p in (tmp_path / f"out{t}").iterdir() if p.suffix != ".zip"})
+        with zipfile.ZipFile(str(prefix) + ".prg.bin.zip") as z:
+            outs[-1]["bin"] = {n: z.read(n) for n in sorted(z.namelist())}
+    assert outs[0] == outs[1]
+    parts = from_msa.split_for_workers(sorted((d).iterdir()), 2)
+    assert len(parts) == 2 and sorted(p for part in parts for p in part) == sorted(d.iterdir())
+
+
+def test_argument_parsing_and_logging_setup(tmp_path, golden_integration, monkeypatch):
+    """python -m make_prg_amd from_msa ... : flags as the reference's, logging to stderr or to --log."""
+    from make_prg_amd import __main__ as cli, device
+    device.set_backend(EmuBackend())
+    case = next(c for c in golden_integration["cases"] if c["case"] == "several")
+    d = write_case(tmp_path, case)
+    cli.main(["from_msa", "-i", str(d), "-o", str(tmp_path / "o1" / "x"), "-O", "p", "-N", "5", "-L", "7"])
+    cli.main(["from_msa", "-i", str(d), "-o", str(tmp_path / "o2" / "x"), "-O", "p", "--log", str(tmp_path / "log.txt")])
+    assert (tmp_path / "o1" / "x.prg.fa").read_text() == (tmp_path / "o2" / "x.prg.fa").read_text()
