@@ -134,6 +134,12 @@ def main():
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MPRG_DIST_BACKEND=gloo + MPRG_DEVICE_MODULO=1: several ranks on ONE GPU, to exercise the multi-rank control flow
+    # on a single-GPU box (RCCL refuses two ranks on one device); the driver's runs use neither
+    dist_backend = os.environ.get("MPRG_DIST_BACKEND", "nccl")
+    if os.environ.get("MPRG_DEVICE_MODULO"):
+        import torch
+        local_rank %= max(torch.cuda.device_count(), 1)          # device_count() does not initialise the GPU
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
@@ -152,6 +158,12 @@ def main():
     import multiprocessing as mp
     ctx = mp.get_context("fork")
     W = max(0, min(args.workers, args.batch))
+    if W > 1:          # stay inside the host: at most half the CPUs and a quarter of the free memory (~4 GiB per worker)
+        try:
+            avail_kib = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1])
+        except Exception:
+            avail_kib = 64 << 20
+        W = max(1, min(W, ncpu // (2 * max(world, 1)), int(avail_kib / (4 << 20) / 4 / max(world, 1))))
     seeds = [rank * 100_000 + i for i in range(args.batch)]
     conns, procs = [], []
     for w in range(W):
@@ -190,7 +202,10 @@ def main():
     import torch.distributed as dist
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(dist_backend)
     device = torch.device("cuda", local_rank)
 
     def barrier():
@@ -218,7 +233,7 @@ def main():
     counters["levels"] = max(c_["levels"] for _, c_ in reports)
     n_streams = args.streams
 
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    t = torch.tensor([dt], dtype=torch.float64, device=device if dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
