@@ -4,9 +4,13 @@
 A step = one pass of the hot path (whole recursion forest + PRG string emission) over one batch of synthetic
 config-C alignments (the 30k-gene pan-genome shape of BASELINE.json: ~100 seqs x 1-3 kb, generator in
 make_prg_amd/utils/synthetic.py) that is already resident in HBM.  Each rank owns `--batch` alignments (weak
-scaling: the directory of MSAs shards with no data-path collective).  Prints ONE JSON line on rank 0.
+scaling: the directory of MSAs shards with no data-path collective) and builds them with `--workers` host worker
+processes that share the rank's GPU (the reference's own parallelism is a process pool over alignments; here the
+processes overlap the array-at-a-time host control of one sub-batch with the kernels of the others).
+Prints ONE JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workers P] [--streams S]
+    --workers 0 runs the same loop inside this process (profiler runs: nothing forks)
 """
 import argparse
 import json
