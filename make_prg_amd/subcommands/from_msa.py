@@ -146,7 +146,8 @@ def _build_batch(msas, loci, options, backend, out: Dict[str, dict]):
             rec["pickle"] = pickle.dumps(builder, protocol=4)
         if ot.binary:
             enc = PrgEncoder()
-            rec["bin"] = np.asarray(enc.encode(prg), dtype="<u4").tobytes()
+            arr = enc.encode_array(prg)
+            rec["bin"] = (arr if arr is not None else np.asarray(enc.encode(prg))).astype("<u4").tobytes()
         if ot.gfa:
             rec["gfa"] = GFA_Output.gfa_text(prg).encode()
         out[locus] = rec

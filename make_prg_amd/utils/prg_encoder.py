@@ -1,4 +1,6 @@
-"""PRG string → little-endian uint32 stream (API of make_prg/utils/prg_encoder.py).  Vectorised host code."""
+"""PRG string → little-endian uint32 stream (API of make_prg/utils/prg_encoder.py).
+encode_array() is the array-at-a-time form the batch driver uses; encode()/_encode_unit() keep the reference's semantics
+and errors unit by unit."""
 from typing import BinaryIO, Dict, List
 
 import numpy as np
@@ -31,10 +33,86 @@ class PrgEncoder:
         self._site_entry_markers: Dict[int, int] = {}
 
     def encode(self, prg: str) -> PRG_Ints:
+        fast = self.encode_array(prg)
+        if fast is not None:
+            return fast.tolist()
+        return self._encode_units(prg)
+
+    def _encode_units(self, prg: str) -> PRG_Ints:
+        """Unit by unit, as the reference (:44-91): also the path that raises its errors."""
         out: List[int] = []
         for unit in prg.split():
             out.extend(self._encode_unit(unit))
         return out
+
+    def encode_array(self, prg: str):
+        """The same stream as a uint32 array, array-at-a-time (a config-C PRG is ~10^5 characters).  Returns None when
+        the text needs the unit-by-unit path: anything but space-separated pure-DNA / pure-digit units, an odd marker
+        seen more than twice, or an encoder that already holds marker counts from an earlier call."""
+        if self._site_entry_markers:
+            return None
+        try:
+            b = np.frombuffer(prg.encode("ascii"), dtype=np.uint8)
+        except UnicodeEncodeError:
+            return None
+        n = len(b)
+        if n == 0:
+            return np.zeros(0, np.uint32)
+        lut = np.zeros(256, np.int64)
+        for ch, v in self.encoding.items():
+            if len(ch) != 1 or not (0 < int(v) < 2 ** 32):
+                return None
+            lut[ord(ch.upper())] = v
+            lut[ord(ch.lower())] = v
+        dna = lut[b]
+        is_dna = dna > 0
+        is_digit = (b >= 48) & (b <= 57)
+        is_space = b == 32
+        if not (is_dna | is_digit | is_space).all() or (is_dna & is_digit).any():
+            return None
+        tok = ~is_space
+        start = tok & ~np.concatenate(([False], tok[:-1]))            # first character of every unit
+        end = tok & ~np.concatenate((tok[1:], [False]))
+        unit_id = np.cumsum(start) - 1
+        n_units = int(start.sum())
+        if n_units == 0:
+            return np.zeros(0, np.uint32)
+        digits_per_unit = np.bincount(unit_id[tok], weights=is_digit[tok], minlength=n_units).astype(np.int64)
+        len_per_unit = np.bincount(unit_id[tok], minlength=n_units)
+        numeric = digits_per_unit == len_per_unit
+        if ((digits_per_unit > 0) & ~numeric).any() or (len_per_unit[numeric] > 18).any():
+            return None                                                 # mixed unit (EncodeError) or absurdly long number
+        # value of every numeric unit: digits weighted by their distance to the unit's end
+        s_pos, e_pos = np.nonzero(start)[0], np.nonzero(end)[0]
+        val = np.zeros(n_units, np.int64)
+        dpos = np.nonzero(is_digit)[0]
+        du = unit_id[dpos]
+        np.add.at(val, du, (b[dpos].astype(np.int64) - 48) * 10 ** (e_pos[du] - dpos))
+        num_units = np.nonzero(numeric)[0]
+        mv = val[num_units]
+        odd = (mv % 2) == 1
+        if odd.any():                                                   # 1st occurrence stays, 2nd becomes the even marker
+            ov = mv[odd]
+            order = np.argsort(ov, kind="stable")
+            sv = ov[order]
+            first = np.concatenate(([True], sv[1:] != sv[:-1]))
+            grp_start = np.maximum.accumulate(np.where(first, np.arange(len(sv)), 0))
+            rank = np.arange(len(sv)) - grp_start
+            if (rank > 1).any():
+                return None                                             # the unit path raises the reference's ValueError
+            bump = np.zeros(len(ov), np.int64)
+            bump[order] = rank
+            mv = mv.copy()
+            mv[np.nonzero(odd)[0]] += bump
+            uniq, cnt = np.unique(ov, return_counts=True)
+            self._site_entry_markers = {int(u): int(c) for u, c in zip(uniq, cnt)}
+        if (mv >= 2 ** 32).any():
+            return None
+        # one output per DNA character, one per numeric unit (at its first character), in text order
+        emit = is_dna | (start & numeric[np.maximum(unit_id, 0)] & tok)
+        out = np.where(is_dna, dna, 0)
+        out[s_pos[num_units]] = mv
+        return out[emit].astype(np.uint32)
 
     @staticmethod
     def write(encoding: List[int], ostream: BinaryIO):
