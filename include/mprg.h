@@ -35,7 +35,8 @@ enum {
   MPRG_V_AUX0 = 10, MPRG_V_AUX1 = 11, MPRG_VIEW_FIELDS = 12
 };
 enum { MPRG_CODE_GAP = 4, MPRG_CODE_N = 11, MPRG_N_CODES = 12 };
-enum { MPRG_IV_MATCH = 0, MPRG_IV_NONMATCH = 1 };
+enum { MPRG_IV_MATCH = 0, MPRG_IV_NONMATCH = 1 /* bit 0 of a triple's type word */,
+       MPRG_IV_PURE = 2 /* bit 1: match interval straight from the scan, view without N / ambiguity codes */ };
 /* per-view status bits written by mprg_partition */
 enum { MPRG_ST_PARTITION_ERROR = 1, MPRG_ST_ALL_N_SLICE = 2 };
 /* per-fit status bits written by the KMeans kernels */

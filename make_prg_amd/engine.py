@@ -246,7 +246,8 @@ class BatchEngine:
         mask = be.download(d_mask, np.uint32, total_cols)
         n_iv = be.download(d_niv, np.int32, n)
         status = be.download(d_status, np.int32, n)
-        iv = be.download(d_iv, np.int32, 3 * total_cols).reshape(-1, 3)
+        iv = be.download(d_iv, np.int32, 3 * total_cols).reshape(-1, 3).copy()
+        iv[:, 2] &= 1                     # bit 1 (MPRG_IV_PURE) is a hint for the array-at-a-time host
         return tab, d_views, d_rowidx, mask, n_iv, iv, status
 
     def _level(self, nodes, frontier, results, failed) -> List[int]:

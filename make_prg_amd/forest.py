@@ -100,7 +100,7 @@ class ForestEngine(BatchEngine):
         T = Growable(dict(msa=np.int64, parent=np.int64, level=np.int64, rowlist=np.int64, col0=np.int64,
                           ncols=np.int64))
         self.T = T
-        self.res_chunks: Dict[str, list] = {k: [] for k in ("kind", "first_child", "n_child", "lvl", "col_off", "leaf_mode",
+        self.res_chunks: Dict[str, list] = {k: [] for k in ("kind", "first_child", "n_child", "lvl", "leaf_mode",
                                                             "reps_off", "nseq", "allele_chars", "node_level", "special")}
         ok = np.nonzero(~self.failed)[0]
         cur = dict(msa=ok, parent=np.full(len(ok), -1, np.int64), level=np.zeros(len(ok), np.int64),
@@ -135,30 +135,45 @@ class ForestEngine(BatchEngine):
     def _forest_level(self, cur):
         be, L = self.be, self.L
         n = len(cur["idx"])
-        tab = self._view_table_arr(cur)
-        total_cols = int(tab[:, 7].sum())
-        cells = float((tab[:, 5] * tab[:, 7]).sum())
-        self.counters["cells_all"] += cells
-        d_views, d_rowidx = be.upload(tab), self.d_pool
-        work, rpc = self._mask_work(tab)
-        d_work, d_mask = be.upload(work), be.zeros(4 * total_cols)
-        be.call("mprg_column_masks", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work),
-                work.shape[0], rpc, be.ptr(d_mask), be.stream, work=cells)
-        d_maxrun, d_stack, d_ivflag = be.zeros(4 * total_cols), be.empty(16 * total_cols), be.zeros(8 * total_cols)
-        d_iv, d_niv, d_status = be.empty(12 * total_cols), be.empty(4 * n), be.empty(4 * n)
-        d_vout, d_ivp, d_ivc = be.empty(32 * n), be.empty(12 * total_cols), be.zeros(4)
-        wr = self._row_chunk_work(tab)
-        d_wr = be.upload(wr)
-        be.call("mprg_partition", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), n, be.ptr(d_mask), L,
-                be.ptr(d_wr), len(wr), be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv),
-                be.ptr(d_status), be.ptr(d_vout), be.ptr(d_ivp), be.ptr(d_ivc), be.stream, work=cells)
-        self.counters["launches"] += 2
-        # the column masks and the per-column interval slots stay on the device: the host reads one record per view
-        # and the sum(n_iv) interval triples
-        vout = be.download(d_vout, np.int32, 8 * n).reshape(n, 8)
-        n_iv, status, first_type = vout[:, 0].astype(np.int64), vout[:, 1], vout[:, 2]
-        has_star, special, iv_off = (vout[:, 3] & 1) != 0, (vout[:, 3] & 2) != 0, vout[:, 4].astype(np.int64)
-        iv = be.download(d_ivp, np.int32, 3 * int(n_iv.sum())).reshape(-1, 3).astype(np.int64)
+        # Children that are match intervals straight from their parent's scan (MPRG_IV_PURE) need no kernel: for the same
+        # rows every column is one plain base, so the node is a leaf with one allele, its columns as they are
+        # (recursion_tree.py:414-420 would find one match interval).  They stay in the level's node range, only the
+        # launches skip them.
+        pure = cur.get("pure")
+        act = np.arange(n) if pure is None else np.nonzero(~pure)[0]
+        na = len(act)
+        sub_cur = cur if na == n else {k: v[act] for k, v in cur.items()}
+        tab_act = self._view_table_arr(sub_cur)
+        tab = tab_act if na == n else np.zeros((n, VF), np.int64)
+        if na != n:
+            tab[act] = tab_act
+        n_iv, status, first_type = np.ones(n, np.int64), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        has_star, special, iv_off = np.zeros(n, bool), np.zeros(n, bool), np.zeros(n, np.int64)
+        iv = np.zeros((0, 3), np.int64)
+        if na:
+            total_cols = int(tab_act[:, 7].sum())
+            cells = float((tab_act[:, 5] * tab_act[:, 7]).sum())
+            self.counters["cells_all"] += cells
+            d_views, d_rowidx = be.upload(tab_act), self.d_pool
+            work, rpc = self._mask_work(tab_act)
+            d_work, d_mask = be.upload(work), be.zeros(4 * total_cols)
+            be.call("mprg_column_masks", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work),
+                    work.shape[0], rpc, be.ptr(d_mask), be.stream, work=cells)
+            d_maxrun, d_stack, d_ivflag = be.zeros(4 * total_cols), be.empty(16 * total_cols), be.zeros(8 * total_cols)
+            d_iv, d_niv, d_status = be.empty(12 * total_cols), be.empty(4 * na), be.empty(4 * na)
+            d_vout, d_ivp, d_ivc = be.empty(32 * na), be.empty(12 * total_cols), be.zeros(4)
+            wr = self._row_chunk_work(tab_act)
+            d_wr = be.upload(wr)
+            be.call("mprg_partition", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), na, be.ptr(d_mask), L,
+                    be.ptr(d_wr), len(wr), be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv),
+                    be.ptr(d_status), be.ptr(d_vout), be.ptr(d_ivp), be.ptr(d_ivc), be.stream, work=cells)
+            self.counters["launches"] += 2
+            # the column masks and the per-column interval slots stay on the device: the host reads one record per view
+            # and the sum(n_iv) interval triples
+            vout = be.download(d_vout, np.int32, 8 * na).reshape(na, 8)
+            n_iv[act], status[act], first_type[act] = vout[:, 0], vout[:, 1], vout[:, 2]
+            has_star[act], special[act], iv_off[act] = (vout[:, 3] & 1) != 0, (vout[:, 3] & 2) != 0, vout[:, 4]
+            iv = be.download(d_ivp, np.int32, 3 * int(vout[:, 0].sum())).reshape(-1, 3).astype(np.int64)
         lvl = len(self.levels)
         self.levels.append(dict(idx=cur["idx"]))
 
@@ -170,24 +185,24 @@ class ForestEngine(BatchEngine):
                     self.errors[mi] = (SequenceCurationError("All sequences in this slice contained N. Redo sequence curation.")
                                        if status[j] & 2 else PartitioningError("Failed interval partitioning"))
         alive = ~self.failed[cur["msa"]]
-        col_off = tab[:, 8]
         is_leaf = alive & (n_iv == 1) & (first_type == 0)
         is_interval = alive & ~is_leaf & ((n_iv > 1) | (cur["parent"] < 0))
         is_cand = alive & ~is_leaf & ~is_interval
 
         R = dict(kind=np.full(n, KIND_LEAF, np.int8), first_child=np.full(n, -1, np.int64), n_child=np.zeros(n, np.int64),
-                 lvl=np.full(n, lvl, np.int64), col_off=col_off.copy(), leaf_mode=np.zeros(n, np.int8),
+                 lvl=np.full(n, lvl, np.int64), leaf_mode=np.zeros(n, np.int8),
                  reps_off=np.full(n, -1, np.int64), nseq=np.ones(n, np.int64), allele_chars=cur["ncols"].copy(),
                  node_level=cur["level"].copy(), special=special)
         R["kind"][is_interval] = KIND_INTERVAL
-        nxt = {k: [] for k in ("msa", "parent", "level", "rowlist", "col0", "ncols", "idx")}
+        nxt = {k: [] for k in ("msa", "parent", "level", "rowlist", "col0", "ncols", "idx", "pure")}
 
-        def add_children(par, rowlist, col0, ncols, level):
+        def add_children(par, rowlist, col0, ncols, level, pure=None):
             cols = dict(msa=cur["msa"][par], parent=cur["idx"][par], level=level, rowlist=rowlist, col0=col0, ncols=ncols)
             idx = self.T.append(**cols)
             for k, v in cols.items():
                 nxt[k].append(v)
             nxt["idx"].append(idx)
+            nxt["pure"].append(np.zeros(len(idx), bool) if pure is None else pure)
             return idx
 
         # ---- children of multi-interval nodes: one child per interval, same rows (recursion_tree.py:439-451)
@@ -197,7 +212,7 @@ class ForestEngine(BatchEngine):
             src = np.repeat(iv_off[pj], cnt) + _seg_arange(cnt)
             par = np.repeat(pj, cnt)
             idx = add_children(par, cur["rowlist"][par], cur["col0"][par] + iv[src, 0], iv[src, 1] - iv[src, 0] + 1,
-                               cur["level"][par])
+                               cur["level"][par], pure=(iv[src, 2] & 2) != 0)
             R["first_child"][pj] = idx[0] + _excl_cumsum(cnt)
             R["n_child"][pj] = cnt
 
@@ -205,13 +220,13 @@ class ForestEngine(BatchEngine):
         cands = np.nonzero(is_cand)[0]
         dleaves = np.nonzero(is_leaf & has_star)[0]
         if len(cands) or len(dleaves):
-            self._forest_cluster(cur, tab, d_views, cands, dleaves, R, add_children, lvl)
+            self._forest_cluster(cur, tab, cands, dleaves, R, add_children, lvl)
         for k, v in R.items():
             self.res_chunks[k].append(v)
-        return {k: (np.concatenate(v) if v else np.zeros(0, np.int64)) for k, v in nxt.items()}
+        return {k: (np.concatenate(v) if v else np.zeros(0, bool if k == "pure" else np.int64)) for k, v in nxt.items()}
 
     # ------------------------------------------------------------------------------------------------ clustering
-    def _forest_cluster(self, cur, tab, d_views, cands, dleaves, R, add_children, lvl):
+    def _forest_cluster(self, cur, tab, cands, dleaves, R, add_children, lvl):
         be, K = self.be, self.L
         sel = np.concatenate([cands, dleaves])
         ncand, nsel = len(cands), len(cands) + len(dleaves)
