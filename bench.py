@@ -60,7 +60,7 @@ def cpu_baseline(n_sample, procs):
     return n_sample / dt, dt
 
 
-def _worker(conn, device, seeds, n_streams, profile_mode):
+def _worker(conn, device, seeds, n_streams, profile_mode, gen_procs=1):
     """One host worker process: owns `n_streams` engines (HIP streams, one host thread each) on GPU `device` and a share
     of the rank's alignments.  The reference's own parallelism is a process pool over MSAs (from_msa `-t`); here the
     processes feed one GPU so that the array-at-a-time host control of several sub-batches overlaps."""
@@ -68,7 +68,7 @@ def _worker(conn, device, seeds, n_streams, profile_mode):
         from concurrent.futures import ThreadPoolExecutor
         from make_prg_amd.backend import HipBackend
         from make_prg_amd.forest import ForestEngine
-        msas = [_gen(s) for s in seeds]
+        msas = make_batch(seeds, gen_procs)             # forks (if at all) before this process touches the GPU
         n_streams = max(1, min(n_streams, len(msas)))
         bes = [HipBackend(device, own_stream=True) for _ in range(n_streams)]
         engs = [ForestEngine(b, max_nesting=5, min_match_length=7) for b in bes]
@@ -126,15 +126,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8192, help="alignments per GPU per step")
+    ap.add_argument("--batch", type=int, default=30000,
+                    help="alignments per GPU per step (default: the whole 30k-gene pan-genome of BASELINE.json, ~15 GB of HBM)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workers", type=int, default=8, help="host worker processes per GPU (each owns a sub-batch)")
+    ap.add_argument("--workers", type=int, default=10, help="host worker processes per GPU (each owns a sub-batch)")
     ap.add_argument("--streams", type=int, default=1, help="host threads / HIP streams per worker process")
     ap.add_argument("--profile", choices=("dominant", "all", "none"), default="all",
                     help="HIP-event timing inside the timed region: the dominant kernel's entry point only, every entry "
                          "point (adds event traffic to every launch), or none")
-    ap.add_argument("--gen-procs", type=int, default=0, help="(unused; the workers generate their own alignments)")
+    ap.add_argument("--gen-procs", type=int, default=0, help="processes per worker that generate its alignments (0 = auto)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -169,10 +170,11 @@ def main():
             avail_kib = 64 << 20
         W = max(1, min(W, ncpu // (2 * max(world, 1)), int(avail_kib / (4 << 20) / 4 / max(world, 1))))
     seeds = [rank * 100_000 + i for i in range(args.batch)]
+    gen_procs = args.gen_procs or max(1, min(16, ncpu // (max(W, 1) * max(world, 1))))
     conns, procs = [], []
     for w in range(W):
         a, b = ctx.Pipe()
-        pr = ctx.Process(target=_worker, args=(b, local_rank, seeds[w::W], args.streams, args.profile), daemon=True)
+        pr = ctx.Process(target=_worker, args=(b, local_rank, seeds[w::W], args.streams, args.profile, gen_procs))
         pr.start()
         conns.append(a); procs.append(pr)
     if W == 0:          # --workers 0: the same worker loop on a thread of this process (rocprofv3 runs: nothing forks)

@@ -8,7 +8,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
-inproc="--workers 0 --streams 4 --no-cpu-baseline --steps 2"
+inproc="--workers 0 --streams 4 --batch 8192 --no-cpu-baseline --steps 2"   # one process generates its alignments serially: smaller batch
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py $inproc > $out/bench_under_rocprof.json 2> $out/prof.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py $inproc > $out/pmc_run_bench.json 2> $out/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py $inproc > $out/pmc_write_bench.json 2> $out/pmc_write.err
