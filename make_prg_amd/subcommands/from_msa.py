@@ -104,6 +104,7 @@ def load_many(files: List[Path], alignment_format: str, procs: int = 1) -> list:
 
 
 BATCH = int(os.environ.get("MPRG_BATCH", "4096"))          # alignments per resident batch
+_CHECK_TREES = os.environ.get("MPRG_CHECK", "") not in ("", "0")
 
 
 def build_shard(files: List[Path], options, backend=None) -> Dict[str, dict]:
@@ -142,7 +143,8 @@ def _build_batch(msas, loci, options, backend, out: Dict[str, dict]):
         if ot.prg:
             builder = PrgBuilder(locus, None, options.alignment_format, options.max_nesting, options.min_match_length,
                                  _root_factory=root_factory)
-            assert builder.build_prg() == prg
+            if _CHECK_TREES:          # MPRG_CHECK=1: re-derive the PRG from the materialised node objects (slow; tests do)
+                assert builder.build_prg() == prg
             rec["pickle"] = pickle.dumps(builder, protocol=4)
         if ot.binary:
             enc = PrgEncoder()
