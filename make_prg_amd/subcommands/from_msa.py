@@ -243,12 +243,16 @@ def _run(options, backend, pool, n_workers):
         raise RuntimeError("One or more output files already exists, aborting run...")
     Path(options.output_prefix).parent.mkdir(parents=True, exist_ok=True)
     mine = shard_files(input_files, rank, world) if world > 1 else input_files
+    import time
+    t0 = time.time()
     if pool is not None and len(mine) >= 2 * n_workers:
         local = {}
         for part in pool.map(_build_part, [(p, options) for p in split_for_workers(mine, n_workers)]):
             local.update(part)
     else:
         local = build_shard(mine, options, backend)
+    logger.info(f"rank {rank}: {len(local)} of {len(mine)} loci built in {time.time() - t0:.1f}s ({n_workers} host workers)")
+    t0 = time.time()
     if dist is not None:
         gathered = [None] * world if rank == 0 else None
         dist.gather_object(local, gathered, dst=0)          # the single exchange of the job
@@ -261,3 +265,4 @@ def _run(options, backend, pool, n_workers):
         logger.error("No PRGs were built, please check errors")
         return
     write_final_files(local, options.output_type, options.output_prefix)
+    logger.info(f"output files written in {time.time() - t0:.1f}s")
