@@ -29,7 +29,7 @@ names = ["k-means++ first centre", "k-means++ further centres", "centre-centre d
          "inertia"]
 for nm, v in zip(names, c):
     print(f"{100 * v / c[:16].sum():6.1f} %  {nm}")
-pn = ["column flags", "serial scan", "pass A (N rows)", "pass B (row comparison)", "merge", "copy-out"]
+pn = ["column flags", "serial scan", "pass A (N rows)", "pass B (row comparison)", "merge", "packed copy", "record + atomic"]
 for nm, v in zip(pn, c[16:]):
     print(f"{100 * v / max(c[16:].sum(), 1):6.1f} %  k_partition: {nm}   ({v / 1e6:.1f} Mcycles)")
 print("fits", eng.counters["fits"], "cycles/fit", c[:16].sum() / max(eng.counters["fits"], 1))
