@@ -185,14 +185,16 @@ class BatchEngine:
         self.load(msas)
         return self.run()
 
-    def run(self, root_level: int = 0, root_is_tree_root: bool = True) -> List[LocusResult]:
+    def run(self, root_level=0, root_is_tree_root=True) -> List[LocusResult]:
         """The hot path on the resident batch: the whole recursion forest, level by level.
-        root_level / root_is_tree_root: re-entry of NodeFactory.build below an existing parent
-        (LeafNode._update_leaf, recursion_tree.py:374-376) starts at the parent's nesting level and does not force a
-        MultiIntervalNode."""
+        root_level / root_is_tree_root (one value, or one per alignment): re-entry of NodeFactory.build below an
+        existing parent (LeafNode._update_leaf, recursion_tree.py:374-376) starts at the parent's nesting level and does
+        not force a MultiIntervalNode."""
         be = self.be
         msas = self._msas
-        self._root_forced = root_is_tree_root
+        per = lambda v: list(v) if isinstance(v, (list, tuple, np.ndarray)) else [v] * len(msas)
+        root_levels, self._root_forced = per(root_level), per(root_is_tree_root)
+        assert len(root_levels) == len(msas) and len(self._root_forced) == len(msas)
         nodes: List[NodeRec] = []
         results = [LocusResult(i, nodes, -1) for i in range(len(msas))]
         frontier: List[int] = []
@@ -201,7 +203,7 @@ class BatchEngine:
                 results[i].error = self.bad[i]
                 continue
             S, C = self.codes[i].shape
-            nodes.append(NodeRec(i, -1, root_level, None, 0, C))
+            nodes.append(NodeRec(i, -1, int(root_levels[i]), None, 0, C))
             results[i].root = len(nodes) - 1
             frontier.append(len(nodes) - 1)
         failed = set(self.bad)
@@ -287,7 +289,7 @@ class BatchEngine:
                     dedupe_leaves.append(j)
                 else:
                     nd.leaf_rows = None       # single sequence == the consensus string
-            elif k > 1 or (nd.parent < 0 and self._root_forced):
+            elif k > 1 or (nd.parent < 0 and self._root_forced[nd.msa]):
                 nd.kind = "interval"
                 for a, b, _t in ivs:
                     nodes.append(NodeRec(nd.msa, ni, nd.level, nd.rows, nd.col0 + int(a), int(b) - int(a) + 1))

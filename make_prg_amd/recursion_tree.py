@@ -160,6 +160,30 @@ class NodeFactory:
             raise res.error
         return materialise(eng, res, alignment, prg_builder, parent_node)
 
+    @staticmethod
+    def build_many(jobs) -> list:
+        """Batched re-entry: jobs = [(alignment, prg_builder, parent_node or None), ...] -> the sub-trees, in job order.
+        What the reference's `update` does leaf by leaf (LeafNode._update_leaf -> NodeFactory.build,
+        recursion_tree.py:374-376) for every touched leaf of every locus is here ONE resident batch per
+        (max_nesting, min_match_length): every alignment starts at its parent's nesting level, none but a tree root
+        is forced to be a MultiIntervalNode.  Node ids are drawn from each job's builder in job order, as a
+        sequential run would.  A job whose alignment fails (SequenceCurationError ...) yields the exception object."""
+        out = [None] * len(jobs)
+        groups = {}
+        for i, (aln, builder, parent) in enumerate(jobs):
+            groups.setdefault((builder.max_nesting, builder.min_match_length), []).append(i)
+        for (max_nesting, min_match_length), idxs in groups.items():
+            eng = BatchEngine(get_backend(), max_nesting, min_match_length)
+            eng.load([jobs[i][0] for i in idxs])
+            results = eng.run(root_level=[0 if jobs[i][2] is None else jobs[i][2].nesting_level for i in idxs],
+                              root_is_tree_root=[jobs[i][2] is None for i in idxs])
+            for i, res in zip(idxs, results):
+                out[i] = (eng, res)
+        for i, (aln, builder, parent) in enumerate(jobs):          # materialise in job order: ids come from the builders
+            eng, res = out[i]
+            out[i] = res.error if res.error is not None else materialise(eng, res, aln, builder, parent)
+        return out
+
 
 def materialise(eng: BatchEngine, res, alignment: MSA, prg_builder, parent_node=None) -> RecursiveTreeNode:
     """Engine records → reference-style node objects; ids drawn from the builder in preorder (reference :48-55)."""

@@ -68,3 +68,29 @@ def test_node_object_host_on_gpu(hip, golden_integration, monkeypatch):
 def test_empty_cluster_relocation_on_gpu(hip):
     from tests.test_kmeans_relocation import check, degenerate_fits
     check(hip, degenerate_fits(8, 80))
+
+
+def test_batched_reentry_below_existing_nodes_on_gpu(hip):
+    """NodeFactory.build_many (the GPU part of the reference's `update`): every touched leaf of every locus in one
+    resident batch, sub-trees and node ids against vectors of the real reference."""
+    import gzip
+    import json
+    import os
+    from make_prg_amd import device
+    from make_prg_amd.recursion_tree import NodeFactory
+    from tests import test_reentry_emulated as tr
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reentry.json.gz"), "rt") as fh:
+        cases = json.load(fh)["cases"]
+    device.set_backend(hip)
+    try:
+        builders = [tr._builder(c, c["first_node_id"]) for c in cases]
+        jobs = [job for c, b in zip(cases, builders) for job in tr._jobs(c, b)]
+        subs = NodeFactory.build_many(jobs)
+        k = 0
+        for c, b in zip(cases, builders):
+            for j in c["jobs"]:
+                assert tr._dump(subs[k]) == j["subtree"], c["file"]
+                k += 1
+            assert b.next_node_id == c["jobs"][-1]["next_node_id"]
+    finally:
+        device.set_backend(None)
