@@ -43,7 +43,7 @@ def _wide_fasta(seed, S, C, p_mut, gaps=True):
 
 @pytest.mark.parametrize("N,L,S,C,p", [(2, 1, 5, 900, 0.02),       # n/(L-1) exceeds the LDS interval stacks: global stacks
                                        (2, 2, 4, 1400, 0.05),
-                                       (1, 7, 3, 9000, 0.002)])    # wider than the LDS column bytes: masks read directly
+                                       (1, 7, 3, 13000, 0.002)])   # wider than the LDS column bytes (PT_COLS): masks read directly
 def test_wide_views_take_the_fallback_paths(emu, N, L, S, C, p, monkeypatch):
     monkeypatch.setattr(pc, "ENGINE", "forest")
     pc.check_vs_oracle(emu, [_wide_fasta(100 + C, S, C, p)], N, L)
