@@ -159,7 +159,53 @@ def read_fasta_alignment(text: str) -> MSA:
 
 
 def _majority_consensus(upper: np.ndarray, upto=None) -> np.ndarray:
-    """utils/seq_utils.py:246-290: one Random(sha256(rows)) draw per column; choice among the most frequent
+    """utils/seq_utils.py:246-290, counts array-at-a-time: per symbol the column counts and the first row it occurs in
+    (the reference's Counter lists tied residues in first-seen order); only the random.Random draws — one per column,
+    each consuming a data-dependent number of bits — stay a loop.  Columns >= upto are not needed by the caller."""
+    rng = random.Random()
+    rng.seed(hashlib.sha256(np.ascontiguousarray(upper).tobytes()).digest())
+    S, C = upper.shape
+    n = C if upto is None else min(C, upto)
+    out = np.full(C, ord("A"), np.uint8)
+    if n == 0 or S == 0:
+        for c in range(n):
+            out[c] = ord(rng.choice("ACGT"))
+        return out
+    sub = upper[:, :n]
+    syms = [int(x) for x in np.nonzero(np.bincount(sub.reshape(-1), minlength=256))[0] if x not in (ord("-"), ord("N"))]
+    if not syms:
+        for c in range(n):
+            out[c] = ord(rng.choice("ACGT"))
+        return out
+    counts = np.empty((len(syms), n), np.int64)
+    first = np.empty((len(syms), n), np.int64)
+    for k, sym in enumerate(syms):
+        hit = sub == sym
+        counts[k] = hit.sum(axis=0)
+        first[k] = hit.argmax(axis=0)
+    top = counts.max(axis=0)
+    tied = counts == top
+    n_tied = tied.sum(axis=0)
+    single = tied.argmax(axis=0).tolist()                             # the only candidate where n_tied == 1
+    chars = [chr(x) for x in syms]
+    one = [[ch] for ch in chars]
+    top_l, n_tied_l, choice, res = top.tolist(), n_tied.tolist(), rng.choice, [65] * n
+    for c in range(n):
+        if top_l[c] == 0:
+            res[c] = ord(choice("ACGT"))
+        elif n_tied_l[c] == 1:
+            res[c] = ord(choice(one[single[c]]))
+        else:
+            ks = np.nonzero(tied[:, c])[0]
+            ks = ks[np.argsort(first[ks, c], kind="stable")]
+            res[c] = ord(choice([chars[k] for k in ks]))
+    out[:n] = res
+    return out
+
+
+def _majority_consensus_by_column(upper: np.ndarray, upto=None) -> np.ndarray:
+    """Plain restatement, column by column with a Counter (tests compare _majority_consensus with it).
+    utils/seq_utils.py:246-290: one Random(sha256(rows)) draw per column; choice among the most frequent
     non-gap non-N residues in first-seen order, or among ACGT if the column has none.  Columns >= upto are not needed
     by the caller (no N at or after them) and are left as 'A'."""
     rng = random.Random()

@@ -95,3 +95,18 @@ def test_random_stream_matches_numpy_randomstate():
     out = np.zeros(1000)
     lib.mprg_oracle_random_sample(ctypes.c_uint32(2), 1000, ctypes.c_void_p(out.ctypes.data))
     assert np.array_equal(out, np.random.RandomState(2).random_sample(1000))
+
+
+def test_load_time_consensus_array_form_equals_the_column_by_column_form():
+    """A0 (utils/seq_utils.py:246-290): the array-at-a-time majority consensus draws the same bases from the same
+    random.Random stream as the plain column-by-column restatement, on random matrices with gaps, N, ambiguity codes."""
+    import numpy as np
+    from make_prg_amd import msa
+    rng = np.random.default_rng(1)
+    alpha = np.frombuffer(b"ACGT-NRYK", np.uint8)
+    for trial in range(200):
+        S, C = int(rng.integers(1, 12)), int(rng.integers(1, 40))
+        p = rng.random(len(alpha))
+        m = alpha[rng.choice(len(alpha), size=(S, C), p=p / p.sum())].astype(np.uint8)
+        upto = None if trial % 3 else int(rng.integers(0, C + 1))
+        assert (msa._majority_consensus(m, upto) == msa._majority_consensus_by_column(m, upto)).all()
