@@ -186,7 +186,13 @@ def main():
 
     def gather(expect="done"):
         out = []
-        for c in conns:
+        for i, c in enumerate(conns):
+            while not c.poll(5.0):          # a worker that died without a word (killed) must not hang the run
+                if procs and not procs[i].is_alive():
+                    sys.stderr.write(f"bench worker {i} exited with code {procs[i].exitcode}\n")
+                    for pr in procs:
+                        pr.terminate()
+                    os._exit(1)
             tag, val = c.recv()
             if tag == "error":
                 sys.stderr.write(val)
