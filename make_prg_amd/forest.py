@@ -287,7 +287,7 @@ class ForestEngine(BatchEngine):
                 be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), be.stream)
         V = be.download(d_V, np.int32, P).astype(np.int64)
         NS = self.k_slots                                      # k values fitted per round (speculation depth)
-        wsz = 2 * D * V + 2 * V + D + 8 + 3 * D * D + NS * N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)   # mprg_kmeans_workspace_doubles
+        wsz = D * V + 2 * V + D + 8 + 3 * D * D + NS * N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)   # mprg_kmeans_workspace_doubles
         ptab[:, 7], ptab[:, 8], ptab[:, 9], ptab[:, 10] = V, _excl_cumsum(D * V), _excl_cumsum(wsz), so
         lo = int(D.sum())
         d_ptab = be.upload(ptab)
