@@ -21,15 +21,45 @@ class UpdateError(Exception):
     pass
 
 
+class SubAlignment:
+    """A node's alignment as a view of its locus' alignment: rows (None = all), column range; all-gap columns are
+    dropped when it is turned into an MSA (remove_columns_full_of_gaps_from_MSA, recursion_tree.py:45).  A batch of
+    30 000 loci has ~5 million nodes; their alignments are only needed by whoever walks the objects (update, debug,
+    pickles), so the nodes keep this descriptor and build the MSA on first use.  All nodes of a locus share `base`,
+    so a pickled tree holds the locus' cells once."""
+    __slots__ = ("base", "rows", "col0", "ncols")
+
+    def __init__(self, base: MSA, rows, col0: int, ncols: int):
+        self.base, self.rows, self.col0, self.ncols = base, rows, col0, ncols
+
+    def materialise(self) -> MSA:
+        data = self.base.data
+        rows = np.arange(data.shape[0]) if self.rows is None else self.rows
+        block = data[rows, self.col0:self.col0 + self.ncols]
+        keep = ~(block == ord("-")).all(axis=0)
+        return MSA(_data=block[:, keep], _ids=[self.base.ids[r] for r in rows],
+                   _descs=[self.base.descriptions[r] for r in rows])
+
+
 class RecursiveTreeNode(ABC):
-    def __init__(self, nesting_level: int, alignment: MSA, parent: Optional["RecursiveTreeNode"], prg_builder,
+    def __init__(self, nesting_level: int, alignment, parent: Optional["RecursiveTreeNode"], prg_builder,
                  children: Optional[List["RecursiveTreeNode"]] = None, node_id: Optional[int] = None):
         self.nesting_level = nesting_level
-        self.alignment = alignment            # already without all-gap columns (device mask)
+        self._alignment = alignment           # MSA (already without all-gap columns) or SubAlignment
         self.parent = parent
         self.prg_builder = prg_builder
         self._node_id = prg_builder.get_next_node_id() if node_id is None else node_id
         self._children: List["RecursiveTreeNode"] = [] if children is None else children
+
+    @property
+    def alignment(self) -> MSA:
+        if isinstance(self._alignment, SubAlignment):
+            self._alignment = self._alignment.materialise()
+        return self._alignment
+
+    @alignment.setter
+    def alignment(self, value):
+        self._alignment = value
 
     @property
     def node_id(self):
@@ -217,12 +247,8 @@ def materialise_forest(eng, mi: int, alignment: MSA, prg_builder) -> RecursiveTr
 
     def make(ni: int, parent) -> RecursiveTreeNode:
         rl = int(t["rowlist"][ni])
-        rows = np.arange(data.shape[0]) if rl < 0 else pool[eng.rl_off[rl]:eng.rl_off[rl] + eng.rl_len[rl]]
-        c0, w = int(t["col0"][ni]), int(t["ncols"][ni])
-        block = data[rows, c0:c0 + w]
-        keep = ~(block == ord("-")).all(axis=0)              # remove_columns_full_of_gaps_from_MSA (recursion_tree.py:45)
-        stored = MSA(_data=block[:, keep], _ids=[alignment.ids[r] for r in rows],
-                     _descs=[alignment.descriptions[r] for r in rows])
+        rows = None if rl < 0 else pool[eng.rl_off[rl]:eng.rl_off[rl] + eng.rl_len[rl]].copy()
+        stored = SubAlignment(alignment, None if rl < 0 else rows, int(t["col0"][ni]), int(t["ncols"][ni]))
         level, kind = int(t["level"][ni]), int(t["kind"][ni])
         if kind == KIND_LEAF:
             return LeafNode(level, stored, parent, prg_builder)
