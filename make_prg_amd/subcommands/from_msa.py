@@ -197,22 +197,39 @@ def split_for_workers(files: List[Path], n: int) -> List[List[Path]]:
     return [p for p in (shard_files(files, w, n) for w in range(n)) if p]
 
 
-def write_final_files(all_loci: Dict[str, dict], output_type, output_prefix: str):
-    """reference utils/input_output_files.py:73-162."""
+def _write_one(all_loci: Dict[str, dict], kind: str, output_prefix: str):
     single = len(all_loci) == 1
-    if output_type.prg:
+    if kind == "fa":
         with open(output_prefix + ".prg.fa", "w") as fh:
             for locus in sorted(all_loci, key=lambda l: l + ".prg.fa"):       # sorted temp-file paths in the reference
                 fh.write(f">{locus}\n{all_loci[locus]['prg']}\n")
+    elif kind == "pickle":
         zip_bytes(Path(output_prefix + ".update_DS.zip"), {l: all_loci[l]["pickle"] for l in all_loci})
-    for flag, key in ((output_type.binary, "bin"), (output_type.gfa, "gfa")):
-        if not flag:
-            continue
-        if single:
-            with open(f"{output_prefix}.prg.{key}", "wb") as fh:
-                fh.write(next(iter(all_loci.values()))[key])
-        else:
-            zip_bytes(Path(f"{output_prefix}.prg.{key}.zip"), {f"{l}.{key}": all_loci[l][key] for l in all_loci})
+    elif single:
+        with open(f"{output_prefix}.prg.{kind}", "wb") as fh:
+            fh.write(next(iter(all_loci.values()))[kind])
+    else:
+        zip_bytes(Path(f"{output_prefix}.prg.{kind}.zip"), {f"{l}.{kind}": all_loci[l][kind] for l in all_loci})
+
+
+def write_final_files(all_loci: Dict[str, dict], output_type, output_prefix: str, parallel: bool = False):
+    """reference utils/input_output_files.py:73-162.  parallel: one forked writer process per output file (the
+    containers are independent; only for a parent that has not initialised the GPU)."""
+    kinds = (["fa", "pickle"] if output_type.prg else []) + (["bin"] if output_type.binary else []) + \
+            (["gfa"] if output_type.gfa else [])
+    if parallel and len(kinds) > 1 and len(all_loci) >= 256:
+        import multiprocessing as mp
+        ctx = mp.get_context("fork")
+        procs = [ctx.Process(target=_write_one, args=(all_loci, k, output_prefix)) for k in kinds]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join()
+        if any(p.exitcode != 0 for p in procs):
+            raise RuntimeError("writing the output files failed")
+    else:
+        for k in kinds:
+            _write_one(all_loci, k, output_prefix)
 
 
 def run(cl_options, backend=None):
@@ -246,8 +263,11 @@ def _run(options, backend, pool, n_workers):
     import time
     t0 = time.time()
     if pool is not None and len(mine) >= 2 * n_workers:
+        # several parts per worker, collected as they finish: the writer-side unpickling of one part overlaps the
+        # building of the others (the per-locus outputs are ~0.5 MB each)
+        n_parts = max(n_workers, min(4 * n_workers, len(mine) // 256))
         local = {}
-        for part in pool.map(_build_part, [(p, options) for p in split_for_workers(mine, n_workers)]):
+        for part in pool.imap_unordered(_build_part, [(p, options) for p in split_for_workers(mine, n_parts)]):
             local.update(part)
     else:
         local = build_shard(mine, options, backend)
@@ -264,5 +284,5 @@ def _run(options, backend, pool, n_workers):
     if not local:
         logger.error("No PRGs were built, please check errors")
         return
-    write_final_files(local, options.output_type, options.output_prefix)
+    write_final_files(local, options.output_type, options.output_prefix, parallel=pool is not None and dist is None)
     logger.info(f"output files written in {time.time() - t0:.1f}s")
