@@ -65,11 +65,17 @@ int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t 
  *      flags (1: some column is not one plain base, i.e. the consensus has a '*' or a gap; 2: N or ambiguity codes
  *      occur), first triple of this view in iv_packed, 0, 0, 0}; iv_packed int32[3*total_cols] = the triples of all
  *      views back to back (a view's triples are contiguous; views in order of completion); iv_count int32[1]
- *      (zeroed) = triples appended. */
+ *      (zeroed) = triples appended.
+ * fused_list / other_list (both NULL, or int32 device lists that together hold 0..n_views-1): the views of fused_list
+ *      are SMALL — at most 512 rows and 1024 columns, rows x pitch <= 8192 bytes (pitch = columns rounded up to 4, +4
+ *      if that is an even number of words), columns / max(min_match_length - 1, 1) + 4 <= 128 — and are handled by one
+ *      workgroup each that holds the view's cells in LDS and computes their column masks and gap runs itself: they
+ *      need NO work items in mprg_column_masks, none in work_rows here, and no scratch. */
 int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
                    const uint32_t *mask, int min_match_length, const int32_t *work_rows, int n_work_rows,
                    uint32_t *maxrun, int32_t *stack, int32_t *ivflag, int32_t *iv, int32_t *n_iv, int32_t *status,
-                   int32_t *view_out, int32_t *iv_packed, int32_t *iv_count, void *stream);
+                   int32_t *view_out, int32_t *iv_packed, int32_t *iv_count, const int32_t *fused_list, int n_fused,
+                   const int32_t *other_list, int n_other, void *stream);
 
 /* A9a/A13/A16 — from_msa/cluster_sequences.py:220-233 (ungap, group identical rows in first-appearance order),
  * utils/seq_utils.py:58-70 (unique gapped / ungapped counts).  Ungap + hash: one workgroup per (view, 256-row chunk)

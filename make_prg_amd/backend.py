@@ -22,7 +22,8 @@ SIGNATURES = {
     "mprg_last_error": (ctypes.c_char_p, []),
     "mprg_device_cus": (c_int, []),
     "mprg_column_masks": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p, c_void_p]),
-    "mprg_partition": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 10),
+    "mprg_partition": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 9 +
+                       [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "mprg_ungap_dedupe": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p, c_int] + [c_void_p] * 13),
     "mprg_kmer_dictionary": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8),
     "mprg_kmer_counts": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7),

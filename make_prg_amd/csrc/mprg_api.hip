@@ -67,11 +67,18 @@ int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t 
 int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
                    const uint32_t *mask, int min_match_length, const int32_t *work_rows, int n_work_rows,
                    uint32_t *maxrun, int32_t *stack, int32_t *ivflag, int32_t *iv, int32_t *n_iv, int32_t *status,
-                   int32_t *view_out, int32_t *iv_packed, int32_t *iv_count, void *stream) {
+                   int32_t *view_out, int32_t *iv_packed, int32_t *iv_count, const int32_t *fused_list, int n_fused,
+                   const int32_t *other_list, int n_other, void *stream) {
   if (n_views <= 0) return 0;
-  LAUNCH(k_gap_runs, n_work_rows, GR_ROWS, stream, arena, views, rowidx, work_rows, mask, maxrun);
-  LAUNCH(k_partition, n_views, BLOCK_VIEW, stream, arena, views, rowidx, mask, min_match_length, maxrun, stack, ivflag,
-         iv, n_iv, status, view_out, iv_packed, iv_count);
+  if (!fused_list && !other_list) { n_fused = 0; n_other = n_views; }
+  else if (n_fused + n_other != n_views) return fail("mprg_partition: the two view lists must cover the views");
+  if (n_work_rows > 0) LAUNCH(k_gap_runs, n_work_rows, GR_ROWS, stream, arena, views, rowidx, work_rows, mask, maxrun);
+  if (n_other > 0)
+    LAUNCH(k_partition, n_other, BLOCK_VIEW, stream, other_list, arena, views, rowidx, mask, min_match_length, maxrun, stack,
+           ivflag, iv, n_iv, status, view_out, iv_packed, iv_count);
+  if (n_fused > 0)
+    LAUNCH(k_partition_fused, n_fused, BLOCK_VIEW, stream, fused_list, arena, views, rowidx, min_match_length, iv, n_iv, status,
+           view_out, iv_packed, iv_count);
   return check_launch("k_partition");
 }
 

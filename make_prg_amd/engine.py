@@ -243,7 +243,7 @@ class BatchEngine:
         d_wr = be.upload(wr)
         be.call("mprg_partition", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), n, be.ptr(d_mask), L,
                 be.ptr(d_wr), len(wr), be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv),
-                be.ptr(d_status), None, None, None, be.stream, work=cells)
+                be.ptr(d_status), None, None, None, None, 0, None, 0, be.stream, work=cells)
         self.counters["launches"] += 2
         mask = be.download(d_mask, np.uint32, total_cols)
         n_iv = be.download(d_niv, np.int32, n)

@@ -12,6 +12,8 @@ prg_builder.py:100-119 + recursion_tree.py:194-300 (traversals).  Row ids are as
 """
 from typing import Dict, List, Optional
 
+import os
+
 import numpy as np
 
 from .backend import MprgError
@@ -20,6 +22,7 @@ from .engine import (BIT_GAP, BIT_N, BITS_IUPAC, MAX_CLUSTERS, N_INIT, PF, ROWS_
 from .msa import CODE_GAP, decode
 
 KIND_LEAF, KIND_INTERVAL, KIND_CLUSTER = 0, 1, 2
+FUSED_VIEWS = os.environ.get("MPRG_FUSED_VIEWS", "1") != "0"     # fused small-view launch shape of mprg_partition
 _ACGT = np.frombuffer(b"ACGT-RYKMSWN????", dtype=np.uint8)
 
 
@@ -155,18 +158,39 @@ class ForestEngine(BatchEngine):
             cells = float((tab_act[:, 5] * tab_act[:, 7]).sum())
             self.counters["cells_all"] += cells
             d_views, d_rowidx = be.upload(tab_act), self.d_pool
-            work, rpc = self._mask_work(tab_act)
-            d_work, d_mask = be.upload(work), be.zeros(4 * total_cols)
-            be.call("mprg_column_masks", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work),
-                    work.shape[0], rpc, be.ptr(d_mask), be.stream, work=cells)
+            # small views (the rule below the root): one fused workgroup each, cells in LDS (include/mprg.h); the others
+            # go through column masks, gap runs and the scan as separate launches
+            Sv, nv = tab_act[:, 5], tab_act[:, 7]
+            pitch = (nv + 3) // 4 * 4
+            pitch = pitch + np.where((pitch // 4) % 2 == 0, 4, 0)
+            fused = (FUSED_VIEWS & (Sv <= 512) & (nv <= 1024) & (Sv * pitch <= 8192) & (nv // max(L - 1, 1) + 4 <= 128)
+                     & (Sv > 0) & (nv > 0))
+            if fused.any() and na >= 32:
+                i_f, i_o = np.nonzero(fused)[0].astype(np.int32), np.nonzero(~fused)[0].astype(np.int32)
+                d_if, d_io = be.upload(i_f), be.upload(i_o)
+                lists = (be.ptr(d_if), len(i_f), be.ptr(d_io), len(i_o))
+            else:
+                i_o = np.arange(na, dtype=np.int32)
+                lists = (None, 0, None, 0)
+            d_mask = be.zeros(4 * total_cols)
+            if len(i_o):
+                tab_o = tab_act[i_o]
+                work, rpc = self._mask_work(tab_o)
+                work[:, 0] = i_o[work[:, 0]]                      # work items name views by their row in the uploaded table
+                d_work = be.upload(work)
+                be.call("mprg_column_masks", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work),
+                        work.shape[0], rpc, be.ptr(d_mask), be.stream, work=float((tab_o[:, 5] * tab_o[:, 7]).sum()))
+                wr = self._row_chunk_work(tab_o)
+                wr[:, 0] = i_o[wr[:, 0]]
+            else:
+                wr = np.zeros((0, 2), np.int32)
             d_maxrun, d_stack, d_ivflag = be.zeros(4 * total_cols), be.empty(16 * total_cols), be.zeros(8 * total_cols)
             d_iv, d_niv, d_status = be.empty(12 * total_cols), be.empty(4 * na), be.empty(4 * na)
             d_vout, d_ivp, d_ivc = be.empty(32 * na), be.empty(12 * total_cols), be.zeros(4)
-            wr = self._row_chunk_work(tab_act)
             d_wr = be.upload(wr)
             be.call("mprg_partition", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), na, be.ptr(d_mask), L,
                     be.ptr(d_wr), len(wr), be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv),
-                    be.ptr(d_status), be.ptr(d_vout), be.ptr(d_ivp), be.ptr(d_ivc), be.stream, work=cells)
+                    be.ptr(d_status), be.ptr(d_vout), be.ptr(d_ivp), be.ptr(d_ivc), *lists, be.stream, work=cells)
             self.counters["launches"] += 2
             # the column masks and the per-column interval slots stay on the device: the host reads one record per view
             # and the sum(n_iv) interval triples
