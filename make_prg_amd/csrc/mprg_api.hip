@@ -1,6 +1,5 @@
 // mprg_api.hip — C ABI (include/mprg.h) over the gfx950 kernels of the from_msa hot path.
 // Build (product):  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared mprg_api.hip -o libmprg_hip.so
-// Build (test-only logic emulation, see mprg_platform.h):  g++ -x c++ -DMPRG_CPU_EMU -O2 -ffp-contract=off -mfma ...
 #include "mprg_platform.h"
 #include "../../include/mprg.h"
 #include <stdio.h>
@@ -17,15 +16,11 @@
 static thread_local char g_err[512] = "";
 static int fail(const char *what) { snprintf(g_err, sizeof g_err, "%s", what); return -1; }
 
-#ifdef MPRG_CPU_EMU
-static int check_launch(const char *) { return 0; }
-#else
 static int check_launch(const char *name) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s: %s", name, hipGetErrorString(e)); return -2; }
   return 0;
 }
-#endif
 
 #define BLOCK_VIEW 256
 #include <stdlib.h>
@@ -37,23 +32,16 @@ static int env_threads(const char *name, int dflt) {
 
 extern "C" {
 
-const char *mprg_version(void) {
-#ifdef MPRG_CPU_EMU
-  return "mprg 0.1 (cpu logic emulation — tests only)";
-#else
-  return "mprg 0.1 (hip gfx950)";
+#ifndef MPRG_BUILD_TAG
+#define MPRG_BUILD_TAG "hip gfx950"
 #endif
-}
+const char *mprg_version(void) { return "mprg 0.2 (" MPRG_BUILD_TAG ")"; }
 const char *mprg_last_error(void) { return g_err; }
 
 int mprg_device_cus(void) {
-#ifdef MPRG_CPU_EMU
-  return 1;
-#else
   int dev = 0; hipDeviceProp_t p;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail("no HIP device");
   return p.multiProcessorCount;
-#endif
 }
 
 int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int32_t *work,
@@ -152,11 +140,7 @@ int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32
                          const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
                          int32_t *scratch, int32_t *out_further, void *stream) {
   if (n_probs <= 0) return 0;
-#ifdef MPRG_CPU_EMU
-  memset(out_further, 0, sizeof(int32_t) * n_probs);
-#else
   if (hipMemsetAsync(out_further, 0, sizeof(int32_t) * n_probs, (hipStream_t)stream) != hipSuccess) return fail("memset");
-#endif
   LAUNCH(k_cluster_majority, n_work_cols, CF_TILE, stream, arena, views, rowidx, prob, work_cols, k, d_of_row, labels,
          assign, scratch);
   LAUNCH(k_cluster_hamming, n_work_rows, CF_TILE, stream, arena, views, rowidx, prob, work_rows, d_of_row, labels,

@@ -1,47 +1,16 @@
-// mprg_platform.h — one kernel source, two builds.
+// mprg_platform.h — shared helpers of the gfx950 kernels (HIP only; built by hipcc --offload-arch=gfx950).
 //
-//  * hipcc --offload-arch=gfx950 (the product): kernels are __global__ functions, PAR_FOR strides a workgroup's
-//    threads over an index range, BARRIER is __syncthreads().
-//  * g++ -DMPRG_CPU_EMU (tests only, tests/emu): the same kernel bodies run one workgroup at a time with PAR_FOR
-//    as a plain loop, so the kernel LOGIC can be checked against the oracle in the GPU-less build container.
-//    The emulation library is never loaded by the product (make_prg_amd loads libmprg_hip.so or fails).
-//
-// Kernel style this imposes: a kernel body is a sequence of PAR_FOR regions separated by BARRIER(); anything kept
-// across a barrier lives in LDS (SHARED) or global memory; code outside a PAR_FOR is workgroup-uniform and any
-// store there is guarded by ONE_THREAD.
+// Loop / launch shorthands used throughout csrc/: PAR_FOR strides the threads of a workgroup over an index range,
+// BARRIER is __syncthreads(), ONE_THREAD guards workgroup-uniform stores.  Wave-level code (ballot, shuffles, DPP-style
+// scans) is written with the HIP intrinsics directly — a wavefront is 64 lanes on CDNA4; the WAVE_* helpers below are
+// the 64-lane idioms several kernels share.
+// (The GPU-less build container checks kernel logic by compiling these same sources with g++ against a test-only
+// stand-in for <hip/hip_runtime.h> that runs workgroups as fibers, tests/emu/include; nothing here knows about it.)
 #pragma once
 #include <stdint.h>
 #include <math.h>
-
-#ifdef MPRG_CPU_EMU
-#include <string.h>
-#include <algorithm>
-#define MPRG_DEV static inline
-#define MPRG_DEVM inline
-#define KERNEL(name, ...) static void name(int mprg_bid, int mprg_nthreads, __VA_ARGS__)
-#define KERNEL_OCC(name, waves, ...) KERNEL(name, __VA_ARGS__)
-#define LAUNCH(name, nblocks, nthreads, stream, ...)                          \
-  do { for (int b_ = 0; b_ < (int)(nblocks); ++b_) name(b_, (int)(nthreads), __VA_ARGS__); } while (0)
-#define BLOCK_ID mprg_bid
-#define N_THREADS mprg_nthreads
-#define PAR_FOR(i, n) for (long long i = 0; i < (long long)(n); ++i)
-#define BARRIER() ((void)0)
-#define ONE_THREAD if (true)
-#define SHARED(T, name, n) T name[n]
-typedef void *mprg_stream_t;
-template <class T> MPRG_DEV T emu_atomic_or(T *p, T v) { T o = *p; *p = o | v; return o; }
-template <class T> MPRG_DEV T emu_atomic_max(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
-template <class T> MPRG_DEV T emu_atomic_min(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
-template <class T> MPRG_DEV T emu_atomic_add(T *p, T v) { T o = *p; *p = o + v; return o; }
-template <class T> MPRG_DEV T emu_atomic_cas(T *p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
-#define ATOMIC_OR(p, v) emu_atomic_or(p, v)
-#define ATOMIC_MAX(p, v) emu_atomic_max(p, v)
-#define ATOMIC_MIN(p, v) emu_atomic_min(p, v)
-#define ATOMIC_ADD(p, v) emu_atomic_add(p, v)
-#define ATOMIC_CAS(p, c, v) emu_atomic_cas(p, c, v)
-#define FMA(a, b, c) fma(a, b, c)
-#else
 #include <hip/hip_runtime.h>
+
 #define MPRG_DEV __device__ __forceinline__
 #define MPRG_DEVM __device__ __forceinline__
 #define KERNEL(name, ...) __global__ void name(__VA_ARGS__)
@@ -50,6 +19,8 @@ template <class T> MPRG_DEV T emu_atomic_cas(T *p, T c, T v) { T o = *p; if (o =
   __attribute__((amdgpu_flat_work_group_size(64, 256), amdgpu_waves_per_eu(waves, waves))) __global__ void name(__VA_ARGS__)
 #define LAUNCH(name, nblocks, nthreads, stream, ...) \
   hipLaunchKernelGGL(name, dim3((unsigned)(nblocks)), dim3((unsigned)(nthreads)), 0, (hipStream_t)(stream), __VA_ARGS__)
+#define LAUNCH_LDS(name, nblocks, nthreads, lds_bytes, stream, ...) \
+  hipLaunchKernelGGL(name, dim3((unsigned)(nblocks)), dim3((unsigned)(nthreads)), (size_t)(lds_bytes), (hipStream_t)(stream), __VA_ARGS__)
 #define BLOCK_ID ((int)blockIdx.x)
 #define N_THREADS ((int)blockDim.x)
 #define PAR_FOR(i, n) for (long long i = threadIdx.x; i < (long long)(n); i += blockDim.x)
@@ -63,7 +34,42 @@ typedef hipStream_t mprg_stream_t;
 #define ATOMIC_ADD(p, v) atomicAdd(p, v)
 #define ATOMIC_CAS(p, c, v) atomicCAS(p, c, v)
 #define FMA(a, b, c) __fma_rn(a, b, c)
-#endif
+
+// ---- 64-lane wavefront idioms
+#define WAVE 64
+MPRG_DEV int wave_lane() { return (int)(threadIdx.x & (WAVE - 1)); }
+MPRG_DEV int wave_id() { return (int)(threadIdx.x >> 6); }
+// number of lanes below this one whose predicate holds, and (out) the wave's total: one ballot, two popcounts
+MPRG_DEV int wave_rank(bool pred, int *total) {
+  const unsigned long long b = __ballot(pred);
+  *total = __popcll(b);
+  return __popcll(b & ((1ull << wave_lane()) - 1ull));
+}
+// inclusive prefix sum over the lanes of a wave (all 64 lanes must call it)
+MPRG_DEV int wave_scan_incl(int v) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) { const int y = __shfl_up(v, d); if (wave_lane() >= d) v += y; }
+  return v;
+}
+MPRG_DEV long long wave_scan_incl_ll(long long v) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) { const long long y = __shfl_up(v, d); if (wave_lane() >= d) v += y; }
+  return v;
+}
+// exclusive prefix sum over ALL threads of a workgroup of up to 1024 threads (every thread calls it, uniform control
+// flow); *total receives the workgroup's sum.  scratch: 17 ints of LDS, reusable after the call returns.
+MPRG_DEV int block_scan_excl(int v, int *scratch, int *total) {
+  const int incl = wave_scan_incl(v);
+  const int nw = (int)((blockDim.x + WAVE - 1) >> 6);
+  if (wave_lane() == WAVE - 1 || threadIdx.x == blockDim.x - 1) scratch[wave_id()] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) { int run = 0; for (int w = 0; w < nw; ++w) { const int t = scratch[w]; scratch[w] = run; run += t; } scratch[16] = run; }
+  __syncthreads();
+  const int out = scratch[wave_id()] + incl - v;
+  *total = scratch[16];
+  __syncthreads();
+  return out;
+}
 
 // ---- cell codes and view accessors (layout: include/mprg.h)
 #define C_GAP 4
@@ -106,7 +112,7 @@ MPRG_DEV int consensus_code(uint32_t mask) {
 
 // ---- diagnostic build only (-DKM_PHASE_TIMING, tools/phase_timing.py): shader-clock cycles thread 0 of every workgroup
 // spends between marks, summed per mark id (0-15: k_kmeans_restart, 16-31: k_partition)
-#if defined(KM_PHASE_TIMING) && !defined(MPRG_CPU_EMU)
+#if defined(KM_PHASE_TIMING)
 __device__ unsigned long long km_phase_cycles[32];
 #define KM_T0() long long km_t0 = clock64()
 #define KM_TPARAM , long long &km_t0

@@ -1,7 +1,8 @@
 """TEST-ONLY stand-in for make_prg_amd.backend.HipBackend.
 
-Compiles make_prg_amd/csrc/mprg_api.hip with g++ -DMPRG_CPU_EMU (see csrc/mprg_platform.h): the same kernel bodies,
-one workgroup at a time, PAR_FOR as a plain loop, "device" buffers as NumPy arrays.  It lets the GPU-less build
+Compiles make_prg_amd/csrc/mprg_api.hip UNCHANGED with g++ against tests/emu/include/hip/hip_runtime.h, a test-only
+stand-in for the HIP runtime header that runs one workgroup at a time with its threads as fibers (barriers, ballots and
+shuffles are rendezvous points); "device" buffers are NumPy arrays.  It lets the GPU-less build
 container check the kernel LOGIC and the host engine against the oracle.  The product never imports this module;
 `-m gpu` tests and everything under make_prg_amd/ use the HIP library only.
 """
@@ -23,12 +24,15 @@ def build_emu(force=False, defines=(), tag="") -> str:
     """`defines`: extra -D switches of test-only variants (e.g. MPRG_TEST_WEAK_HASH: every row hash collides, so the
     exact-comparison fallbacks run); `tag` names the variant's library."""
     lib = LIB.replace(".so", f"{tag}.so")
-    srcs = [os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR)] + [os.path.join(ROOT, "include", "mprg.h")]
+    srcs = [os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR)] + [os.path.join(ROOT, "include", "mprg.h"),
+            os.path.join(HERE, "include", "hip", "hip_runtime.h")]
     newest = max(os.path.getmtime(s) for s in srcs)
     if force or not os.path.exists(lib) or os.path.getmtime(lib) < newest:
         os.makedirs(os.path.dirname(lib), exist_ok=True)
-        subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-DMPRG_CPU_EMU", "-O2", "-ffp-contract=off", "-mfma",
-                               "-fPIC", "-shared", "-Wno-unused-function"] + [f"-D{d}" for d in defines] +
+        subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-mfma",
+                               "-I", os.path.join(HERE, "include"), '-DMPRG_BUILD_TAG="cpu emulation, tests only"',
+                               "-fPIC", "-shared", "-Wno-unused-function", "-Wno-attributes", "-Wno-unknown-pragmas"] +
+                              [f"-D{d}" for d in defines] +
                               [os.path.join(SRC_DIR, "mprg_api.hip"), "-o", lib])
     return lib
 
