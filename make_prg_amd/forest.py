@@ -23,6 +23,9 @@ from .msa import CODE_GAP, decode
 
 KIND_LEAF, KIND_INTERVAL, KIND_CLUSTER = 0, 1, 2
 FUSED_VIEWS = os.environ.get("MPRG_FUSED_VIEWS", "1") != "0"     # fused small-view launch shape of mprg_partition
+KMEANS_LDS = os.environ.get("MPRG_KMEANS_LDS", "1") != "0"       # LDS-resident KMeans fits (0: global-memory kernels only)
+# dynamic-LDS size classes of mprg_kmeans_fit_lds launches: 4, 3, 2 and 1 workgroups per CU (160 KiB of LDS per CU)
+LDS_CLASSES = np.asarray([40 * 1024 - 64, 53 * 1024 - 64, 80 * 1024 - 64, 160 * 1024 - 64], np.int64)
 _ACGT = np.frombuffer(b"ACGT-RYKMSWN????", dtype=np.uint8)
 
 
@@ -311,7 +314,12 @@ class ForestEngine(BatchEngine):
                 be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), be.stream)
         V = be.download(d_V, np.int32, P).astype(np.int64)
         NS = self.k_slots                                      # k values fitted per round (speculation depth)
-        wsz = D * V + 2 * V + D + 8 + 3 * D * D + NS * N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)   # mprg_kmeans_workspace_doubles
+        # LDS-resident fits (the rule) need the problem's common workspace only; the per-restart slots are for fits that
+        # do not fit a CU's LDS at some k (their largest k decides: the need grows with k) and for the speculative rounds
+        kmax_p = np.minimum(MAX_CLUSTERS, np.maximum(D - 1, 2)).astype(np.int32)
+        G_kmax, _ = self._lds_plan(D, V, kmax_p)
+        self._lds_ok = (G_kmax > 0) & (NS == 1) & KMEANS_LDS
+        wsz = D * V + 2 * V + D + 8 + 3 * D * D + np.where(self._lds_ok, 0, NS * N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512))   # mprg_kmeans_workspace_doubles
         ptab[:, 7], ptab[:, 8], ptab[:, 9], ptab[:, 10] = V, _excl_cumsum(D * V), _excl_cumsum(wsz), so
         lo = int(D.sum())
         d_ptab = be.upload(ptab)
@@ -340,26 +348,14 @@ class ForestEngine(BatchEngine):
             active = active[(num_clusters[active] <= MAX_CLUSTERS) & (num_clusters[active] != D[active])]
             if not len(active):
                 break
+            active, st, info = self._kmeans_round(active, k, D, V, int(uoff_arr[k]), d_ptab, d_uni, d_x, d_ws, d_labels)
             nA = len(active)
-            ki = np.empty((nA, 5), np.int32)
-            ki[:, 0], ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = active, k, 0, uoff_arr[k], 0
-            d_ki, d_st, d_info = be.upload(ki), be.zeros(4 * nA), be.empty(64 * nA)
-            be.call("mprg_kmeans_restarts", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_uni), be.ptr(d_ws),
-                    be.ptr(d_st), be.stream)
-            be.call("mprg_kmeans_select", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_x), be.ptr(d_ws),
-                    be.ptr(d_labels), be.ptr(d_info), be.stream)
-            self.counters["launches"] += 2
-            st = be.download(d_st, np.int32, nA)
-            info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
             if (st & 2).any():
                 raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
                                 "is not restated on the device; refusing to continue with a possibly different result")
             kb = float((8.0 * D[active] * V[active] * (info[:, 4] + N_INIT)).sum())
             self.counters["fits"] += nA
             self.counters["kmeans_bytes"] += kb
-            if be.profile is not None and be.profile.get("mprg_kmeans_restarts"):
-                a0, a1, _ = be.profile["mprg_kmeans_restarts"][-1]
-                be.profile["mprg_kmeans_restarts"][-1] = (a0, a1, kb)
             good = info[:, 3].astype(np.int64) >= k
             num_clusters[active[~good]] -= 1                     # cluster_sequences.py:267-273: revert and stop
             active = active[good]
@@ -475,6 +471,61 @@ class ForestEngine(BatchEngine):
         idx = add_children(par, base + np.arange(len(sizes)), cur["col0"][par], cur["ncols"][par], R["node_level"][par])
         R["first_child"][pj] = idx[0] + child_off
         R["n_child"][pj] = nchild
+
+    # ------------------------------------------------------------------------------------------------ KMeans rounds
+    def _lds_plan(self, D, V, k, limit=None):
+        """(G, dynamic LDS bytes) per fit for mprg_kmeans_fit_lds; G == 0: the fit does not fit a CU's LDS."""
+        n = len(D)
+        Dv, Vv, kv = (np.ascontiguousarray(D, np.int64), np.ascontiguousarray(V, np.int64), np.ascontiguousarray(k, np.int32))
+        G, nbytes = np.zeros(n, np.int32), np.zeros(n, np.int64)
+        if n:
+            self.be.lib.mprg_kmeans_lds_plan(Dv.ctypes.data, Vv.ctypes.data, kv.ctypes.data, n, N_INIT,
+                                             int(limit or (1 << 40)), G.ctypes.data, nbytes.ctypes.data)
+        return G, nbytes
+
+    def _kmeans_round(self, active, k, D, V, uoff, d_ptab, d_uni, d_x, d_ws, d_labels):
+        """One k of the reference's loop (cluster_sequences.py:262-266) for the problems `active`: every fit whose working
+        set fits a CU's LDS goes to mprg_kmeans_fit_lds — one launch per LDS size class, so that small fits share a CU —
+        the others to the global-memory kernels.  Returns (active reordered by launch, status, km_info rows)."""
+        be = self.be
+        G, nbytes = self._lds_plan(D[active], V[active], np.full(len(active), k, np.int32))
+        G = np.where(self._lds_ok[active], G, 0)
+        cls = np.searchsorted(LDS_CLASSES, nbytes, side="left")           # 0..len-1; G == 0 -> its own class at the end
+        cls = np.where(G > 0, cls, len(LDS_CLASSES))
+        order = np.lexsort((-(D[active] * V[active]), cls))              # class, then biggest fits first
+        active, G, nbytes, cls = active[order], G[order], nbytes[order], cls[order]
+        nA = len(active)
+        ki = np.empty((nA, 5), np.int32)
+        ki[:, 0], ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = active, k, G, uoff, 0
+        d_ki, d_st, d_info = be.upload(ki), be.zeros(4 * nA), be.empty(64 * nA)
+        timed = []                                                      # (entry point, its event slot, class) when profiling
+        for c in np.unique(cls):
+            m = np.nonzero(cls == c)[0]
+            lo, n = int(m[0]), len(m)
+            off = lambda buf, b: _Offset(be, buf, b * lo)
+            if c < len(LDS_CLASSES):
+                name = "mprg_kmeans_fit_lds"
+                be.call(name, be.ptr(d_ptab), be.ptr(off(d_ki, 20)), n, N_INIT, be.ptr(d_uni), be.ptr(d_x),
+                        be.ptr(d_ws), be.ptr(d_labels), be.ptr(off(d_info, 64)), be.ptr(off(d_st, 4)), int(nbytes[m].max()),
+                        be.stream)
+                self.counters["launches"] += 1
+                self.counters["fits_lds"] = self.counters.get("fits_lds", 0) + n
+            else:
+                name = "mprg_kmeans_restarts"
+                be.call(name, be.ptr(d_ptab), be.ptr(off(d_ki, 20)), n, N_INIT, be.ptr(d_uni), be.ptr(d_ws),
+                        be.ptr(off(d_st, 4)), be.stream)
+                be.call("mprg_kmeans_select", be.ptr(d_ptab), be.ptr(off(d_ki, 20)), n, N_INIT, be.ptr(d_x), be.ptr(d_ws),
+                        be.ptr(d_labels), be.ptr(off(d_info, 64)), be.stream)
+                self.counters["launches"] += 2
+            if be.profile is not None and be.profile.get(name):
+                timed.append((name, len(be.profile[name]) - 1, c))
+        st = be.download(d_st, np.int32, nA)
+        info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
+        for name, slot, c in timed:          # algorithmic bytes are known only after the fits: 8 D V (Elkan iterations + n_init)
+            m = cls == c
+            a0, a1, _ = be.profile[name][slot]
+            be.profile[name][slot] = (a0, a1, float((8.0 * D[active[m]] * V[active[m]] * (info[m, 4] + N_INIT)).sum()))
+        return active, st, info
 
     # ------------------------------------------------------------------------------------------------ tables
     def _finalize_tables(self):

@@ -45,6 +45,8 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->mu
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 enum { hipMemcpyDeviceToDevice = 3 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
 
 namespace emu {
 enum { RUNNABLE = 0, AT_BARRIER = 1, AT_WAVE = 2, DONE = 3 };

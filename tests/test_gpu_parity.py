@@ -42,6 +42,21 @@ def test_kmeans_known_answers(hip, golden_kmeans):
         assert g["n_iter"] == f["n_iter"]
 
 
+def test_kmeans_known_answers_lds_resident_fits(hip, golden_kmeans):
+    """The same scikit-learn answers through mprg_kmeans_fit_lds (one workgroup per fit, working set in LDS), once with
+    every restart resident and once with an LDS budget that forces several passes of restarts."""
+    from tests.kmeans_direct import run_kmeans_fits
+    fits = golden_kmeans["fits"]
+    for limit in (None, 70000):
+        before = run_kmeans_fits.lds_fits
+        got = run_kmeans_fits(hip, fits, path="lds", lds_limit=limit)
+        assert run_kmeans_fits.lds_fits - before == len(fits)
+        for g, f in zip(got, fits):
+            assert g["labels"] == f["labels"]
+            assert g["inertia_hex"] == f["inertia"]
+            assert g["n_iter"] == f["n_iter"]
+
+
 def test_batch_of_fresh_seeds_against_oracle(hip):
     from make_prg_amd.utils.synthetic import synth_config_fasta
     texts = [synth_config_fasta("B", s) for s in range(100, 148)]
@@ -67,7 +82,10 @@ def test_node_object_host_on_gpu(hip, golden_integration, monkeypatch):
 
 def test_empty_cluster_relocation_on_gpu(hip):
     from tests.test_kmeans_relocation import check, degenerate_fits
-    check(hip, degenerate_fits(8, 80))
+    fits = degenerate_fits(8, 80)
+    check(hip, fits)
+    check(hip, fits, path="lds")
+    check(hip, fits, path="lds", lds_limit=12000)
 
 
 def test_batched_reentry_below_existing_nodes_on_gpu(hip):
