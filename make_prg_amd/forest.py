@@ -23,7 +23,10 @@ from .msa import CODE_GAP, decode
 
 KIND_LEAF, KIND_INTERVAL, KIND_CLUSTER = 0, 1, 2
 FUSED_VIEWS = os.environ.get("MPRG_FUSED_VIEWS", "1") != "0"     # fused small-view launch shape of mprg_partition
-KMEANS_LDS = os.environ.get("MPRG_KMEANS_LDS", "1") != "0"       # LDS-resident KMeans fits (0: global-memory kernels only)
+# LDS-resident KMeans fits (mprg_kmeans_fit_lds).  Measured on MI355X (profiles/r02/kmeans_lds.md): 2.2x shorter per fit
+# than the global-memory kernels, but ~100 KB of LDS per fit leaves 1-2 fits per CU instead of 4, so the batch rate is
+# 0.8x: off by default until the per-fit footprint is halved (centres updated in place)
+KMEANS_LDS = os.environ.get("MPRG_KMEANS_LDS", "0") != "0"
 # dynamic-LDS size classes of mprg_kmeans_fit_lds launches: 4, 3, 2 and 1 workgroups per CU (160 KiB of LDS per CU)
 LDS_CLASSES = np.asarray([40 * 1024 - 64, 53 * 1024 - 64, 80 * 1024 - 64, 160 * 1024 - 64], np.int64)
 _ACGT = np.frombuffer(b"ACGT-RYKMSWN????", dtype=np.uint8)

@@ -24,11 +24,14 @@ eng.run_forest()
 be.synchronize()
 be.lib.mprg_debug_phase_cycles(out, 0)
 c = np.array(list(out), dtype=np.float64)
-names = ["k-means++ first centre", "k-means++ further centres", "centre-centre distances", "sample-centre distances",
+lds_names = ["load into LDS", "k-means++ pick", "k-means++ score", "first centres", "centre-centre distances",
+             "sample-centre distances", "init bounds / E-step", "M-step", "shifts + norms", "bounds + stop test", "inertia",
+             "best restart", "predict"]
+names = lds_names if (F.KMEANS_LDS and eng.counters.get("fits_lds")) else ["k-means++ first centre", "k-means++ further centres", "centre-centre distances", "sample-centre distances",
          "init bounds / E-step", "M-step sums", "cluster sizes / relocation", "average centres", "shift, bounds, stop test",
          "inertia"]
 for nm, v in zip(names, c):
-    print(f"{100 * v / c[:16].sum():6.1f} %  {nm}")
+    print(f"{100 * v / c[:16].sum():6.1f} %  {nm}   ({v / max(eng.counters['fits'], 1):.0f} cycles per fit)")
 pn = ["column flags", "serial scan", "pass A (N rows)", "pass B (row comparison)", "merge", "packed copy", "record + atomic"]
 for nm, v in zip(pn, c[16:]):
     print(f"{100 * v / max(c[16:].sum(), 1):6.1f} %  k_partition: {nm}   ({v / 1e6:.1f} Mcycles)")
