@@ -5,8 +5,11 @@ import os
 import sys
 
 from . import __version__
-from .subcommands import from_msa
+from .subcommands import from_msa, update
 from .subcommands.output_type import OutputType
+
+
+MAX_WORKERS_PER_GPU = 10
 
 
 def main(argv=None):
@@ -15,14 +18,14 @@ def main(argv=None):
     parser.add_argument("-V", "--version", action="version", version=__version__)
     subparsers = parser.add_subparsers(title="Available subcommands", help="", metavar="")
     msa_parser = from_msa.register_parser(subparsers)
-    for par in (msa_parser,):
+    update_parser = update.register_parser(subparsers)
+    for par in (msa_parser, update_parser):
         par.add_argument("-O", "--output-type", default="a", type=OutputType,
                          help="p: PRG, b: Binary, g: GFA, a: All. Combinations are allowed i.e., gb: GFA and Binary. "
                               "Default: %(default)s")
         par.add_argument("-F", "--force", action="store_true", default=False, help="Force overwrite previous output")
         par.add_argument("-t", "--threads", action="store", type=int, default=1,
-                         help="Host worker processes per GPU (each builds a part of the rank's alignments on the rank's "
-                              "device); 0: one per CPU. Default: %(default)d")
+                         help="Number of threads. 0 will use all available. Default: %(default)d")
         par.add_argument("-v", "--verbose", action="count", default=0, help="Increase output verbosity")
         par.add_argument("--log", help="Path to write log to. Default is stderr")
     args = parser.parse_args(argv)
@@ -30,7 +33,10 @@ def main(argv=None):
         level = [logging.INFO, logging.DEBUG, logging.DEBUG][min(args.verbose, 2)]
         logging.basicConfig(level=level, **({"filename": args.log} if args.log else {"stream": sys.stderr}))
         if args.threads == 0:
-            args.threads = os.cpu_count()
+            # "all available": host worker processes per GPU stop paying at ~10 (16 are slower than 10 —
+            # the processes' queues are time-sliced on the one device), and the ranks of a node share its cores
+            local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+            args.threads = max(1, min(MAX_WORKERS_PER_GPU, (os.cpu_count() or 1) // local_world))
         args.func(args)
     else:
         parser.print_help()

@@ -604,6 +604,8 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool =
     n = len(t["msa"])
     M = len(self._msas)
     if n == 0:
+        self.prg_index_arrays = (np.zeros(0, np.int64),) * 3
+        self.node_id, self.site_count = np.zeros(0, np.int64), np.zeros(M, np.int64)
         return [None] * M
     msa, parent, kind, nch, fch = t["msa"], t["parent"], t["kind"], t["n_child"], t["first_child"]
     meta = self.meta_arr

@@ -155,7 +155,25 @@ class LeafNode(RecursiveTreeNode):
             if do_indexing:
                 self.prg_builder.update_PRG_index(start, end, node=self)
 
-    # ---- update hooks (the `update` sub-command itself is out of scope; the re-entry into the builder is kept)
+    # ---- update hooks (reference :302-391)
+    def add_data_to_batch_update(self, update_data):
+        """One (sub-)variant that falls into this leaf: the new allele, padded with the sample's alleles in the leaf's
+        other indexed PRG intervals (a leaf with several alleles is indexed once per allele) — reference :304-342."""
+        from .update.ml_path import MLPathError
+        key = update_data.ml_path_node_key
+        if key not in self.indexed_PRG_intervals:
+            raise UpdateError(f"PRG interval {key} not found in indexed PRG intervals for node: {self.indexed_PRG_intervals}")
+        parts = []
+        for interval in sorted(self.indexed_PRG_intervals):
+            if interval == key:
+                parts.append(update_data.new_node_sequence)
+            else:
+                try:
+                    parts.append(update_data.ml_path.get_node_given_interval_in_PRG_space(interval).sequence)
+                except MLPathError:
+                    pass
+        self.new_sequences.add("".join(parts))
+
     def add_indexed_PRG_interval(self, interval: Tuple[int, int]):
         self.indexed_PRG_intervals.add(interval)
 
@@ -166,16 +184,23 @@ class LeafNode(RecursiveTreeNode):
         if self.new_sequences:
             self._update_leaf()
 
-    def _update_leaf(self):
+    def updated_alignment(self) -> MSA:
+        """The aligner's part of _update_leaf (reference :366-371)."""
         assert self.prg_builder.aligner is not None, "Cannot make updates without a Multiple Sequence Aligner."
-        updated = self.prg_builder.aligner.get_updated_alignment(current_alignment=self.alignment,
-                                                                 new_sequences=self.new_sequences)
-        new_node = NodeFactory.build(updated, self.prg_builder, self.parent)
+        return self.prg_builder.aligner.get_updated_alignment(current_alignment=self.alignment,
+                                                              new_sequences=self.new_sequences)
+
+    def replace_by(self, new_node: "RecursiveTreeNode"):
+        """The tree surgery of _update_leaf (reference :378-388): the rebuilt sub-tree takes this leaf's place and the
+        builder's PRG index, now stale to the right of the site, is cleared."""
         if self.is_root():
             self.prg_builder.replace_root(new_node)
         else:
             self.parent.replace_child(self, new_node)
         self.prg_builder.clear_PRG_index()
+
+    def _update_leaf(self):
+        self.replace_by(NodeFactory.build(self.updated_alignment(), self.prg_builder, self.parent))
 
 
 class NodeFactory:
@@ -238,8 +263,9 @@ def materialise(eng: BatchEngine, res, alignment: MSA, prg_builder, parent_node=
     return make(res.root, parent_node)
 
 
-def materialise_forest(eng, mi: int, alignment: MSA, prg_builder) -> RecursiveTreeNode:
-    """Same as materialise() for one tree of a forest.ForestEngine batch (assemble_prgs() must have run)."""
+def materialise_forest(eng, mi: int, alignment: MSA, prg_builder, leaf_of: Optional[dict] = None) -> RecursiveTreeNode:
+    """Same as materialise() for one tree of a forest.ForestEngine batch (assemble_prgs() must have run).
+    leaf_of (optional dict) receives {node table index: LeafNode} so that the caller can attach the batch's PRG index."""
     from .forest import KIND_INTERVAL, KIND_LEAF
     t = eng.tab
     data = alignment.data
@@ -251,7 +277,10 @@ def materialise_forest(eng, mi: int, alignment: MSA, prg_builder) -> RecursiveTr
         stored = SubAlignment(alignment, None if rl < 0 else rows, int(t["col0"][ni]), int(t["ncols"][ni]))
         level, kind = int(t["level"][ni]), int(t["kind"][ni])
         if kind == KIND_LEAF:
-            return LeafNode(level, stored, parent, prg_builder)
+            leaf = LeafNode(level, stored, parent, prg_builder)
+            if leaf_of is not None:
+                leaf_of[ni] = leaf
+            return leaf
         node = (MultiIntervalNode if kind == KIND_INTERVAL else MultiClusterNode)(level, stored, parent, prg_builder, [])
         for j in range(int(t["n_child"][ni])):
             node._children.append(make(int(t["first_child"][ni]) + j, node))

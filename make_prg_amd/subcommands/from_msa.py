@@ -71,17 +71,23 @@ def _dist():
     return dist.get_rank(), dist.get_world_size(), dist
 
 
+def balanced_parts(files: List[Path], n_parts: int) -> List[List[Path]]:
+    """Cost-balanced split: longest-processing-time greedy on file size (gene sizes are skewed), every file stat-ed once,
+    one pass with a heap of part loads.  Deterministic (ties by path and part number)."""
+    import heapq
+    sized = sorted(((-f.stat().st_size, str(f), f) for f in files))
+    heap = [(0, p) for p in range(n_parts)]
+    parts: List[List[Path]] = [[] for _ in range(n_parts)]
+    for neg, _, f in sized:
+        load, p = heapq.heappop(heap)
+        parts[p].append(f)
+        heapq.heappush(heap, (load - neg, p))
+    return parts
+
+
 def shard_files(files: List[Path], rank: int, world: int) -> List[Path]:
-    """Cost-balanced shard: longest-processing-time greedy on file size (gene sizes are skewed)."""
-    order = sorted(files, key=lambda p: (-p.stat().st_size, str(p)))
-    loads = [0] * world
-    mine = []
-    for f in order:
-        r = min(range(world), key=lambda i: (loads[i], i))
-        loads[r] += f.stat().st_size
-        if r == rank:
-            mine.append(f)
-    return mine
+    """This rank's cost-balanced shard of the input list."""
+    return balanced_parts(files, world)[rank]
 
 
 def _load_one(args):
@@ -128,6 +134,21 @@ def build_shard(files: List[Path], options, backend=None) -> Dict[str, dict]:
     return out
 
 
+def locus_record(locus: str, prg: str, builder, output_type) -> dict:
+    """The per-locus output bytes of a run: PRG text, pickled builder (update_DS member), binary PRG, GFA — what the
+    reference writes to per-locus temp files (subcommands/from_msa.py:114-133, subcommands/update.py:128-141)."""
+    rec = dict(prg=prg)
+    if output_type.prg:
+        rec["pickle"] = pickle.dumps(builder, protocol=4)
+    if output_type.binary:
+        enc = PrgEncoder()
+        arr = enc.encode_array(prg)
+        rec["bin"] = (arr if arr is not None else np.asarray(enc.encode(prg))).astype("<u4").tobytes()
+    if output_type.gfa:
+        rec["gfa"] = GFA_Output.gfa_text(prg).encode()
+    return rec
+
+
 def _build_batch(msas, loci, options, backend, out: Dict[str, dict]):
     from ..device import get_backend
     from ..prg_builder import PrgBuilder
@@ -137,33 +158,26 @@ def _build_batch(msas, loci, options, backend, out: Dict[str, dict]):
     be = backend or get_backend()
     ot = options.output_type
 
-    def emit(locus, msa, prg, root_factory):
-        logger.info(f"Writing output files of locus {locus}")
-        rec = dict(prg=prg)
-        if ot.prg:
-            builder = PrgBuilder(locus, None, options.alignment_format, options.max_nesting, options.min_match_length,
-                                 _root_factory=root_factory)
-            if _CHECK_TREES:          # MPRG_CHECK=1: re-derive the PRG from the materialised node objects (slow; tests do)
-                assert builder.build_prg() == prg
-            rec["pickle"] = pickle.dumps(builder, protocol=4)
-        if ot.binary:
-            enc = PrgEncoder()
-            arr = enc.encode_array(prg)
-            rec["bin"] = (arr if arr is not None else np.asarray(enc.encode(prg))).astype("<u4").tobytes()
-        if ot.gfa:
-            rec["gfa"] = GFA_Output.gfa_text(prg).encode()
-        out[locus] = rec
+    def new_builder(locus, root_factory):
+        return PrgBuilder(locus, None, options.alignment_format, options.max_nesting, options.min_match_length,
+                          _root_factory=root_factory)
 
     # the array-at-a-time host assumes unique row ids inside an alignment; the rest keeps the id-based node host
-    uniq = [i for i, m in enumerate(msas) if len(set(m.ids)) == len(m.ids)]
-    dup = [i for i in range(len(msas)) if i not in set(uniq)]
+    is_uniq = [len(set(m.ids)) == len(m.ids) for m in msas]
+    uniq = [i for i, u in enumerate(is_uniq) if u]
+    dup = [i for i, u in enumerate(is_uniq) if not u]
     if uniq:
         from ..forest import ForestEngine
         from ..recursion_tree import materialise_forest
         eng = ForestEngine(be, options.max_nesting, options.min_match_length)
         eng.load([msas[i] for i in uniq])
         eng.run_forest()
-        prgs = eng.assemble_prgs()
+        prgs = eng.assemble_prgs(want_index=ot.prg)
+        if ot.prg:          # rows of the batch's PRG index grouped by alignment
+            ix_leaf, ix_s, ix_e = eng.prg_index_arrays
+            ix_msa = eng.tab["msa"][ix_leaf]
+            ix_order = np.argsort(ix_msa, kind="stable")
+            ix_bounds = np.searchsorted(ix_msa[ix_order], np.arange(len(uniq) + 1))
         for j, i in enumerate(uniq):
             if prgs[j] is None:
                 err = eng.errors[j]
@@ -171,7 +185,24 @@ def _build_batch(msas, loci, options, backend, out: Dict[str, dict]):
                     raise err
                 logger.warning(f"Skipping building PRG for {loci[i]}. Error: {err}")
                 continue
-            emit(loci[i], msas[i], prgs[j], lambda b, j=j, i=i: materialise_forest(eng, j, msas[i], b))
+            logger.info(f"Writing output files of locus {loci[i]}")
+            builder = None
+            if ot.prg:
+                # the pickled builder must be what the reference serialises AFTER build_prg() (subcommands/from_msa.py:
+                # 123-127): site counter advanced, every leaf allele in prg_index and in its leaf's indexed intervals —
+                # `update` looks leaves up by these keys.  They come from the batch's index arrays, not from a second
+                # traversal of the node objects.
+                leaf_of = {}
+                builder = new_builder(loci[i], lambda b, j=j, i=i: materialise_forest(eng, j, msas[i], b, leaf_of))
+                builder.site_num = 5 + 2 * int(eng.site_count[j])
+                rows = ix_order[ix_bounds[j]:ix_bounds[j + 1]]
+                for ni, a, e in zip(ix_leaf[rows].tolist(), ix_s[rows].tolist(), ix_e[rows].tolist()):
+                    builder.update_PRG_index(a, e, leaf_of[ni])
+                if _CHECK_TREES:          # MPRG_CHECK=1: re-derive everything from the node objects (slow; tests do)
+                    index, site = dict(builder.prg_index), builder.site_num
+                    builder.clear_PRG_index()
+                    assert builder.build_prg() == prgs[j] and builder.prg_index == index and builder.site_num == site
+            out[loci[i]] = locus_record(loci[i], prgs[j], builder, ot)
     if dup:
         eng2 = BatchEngine(be, options.max_nesting, options.min_match_length)
         results = eng2.build([msas[i] for i in dup])
@@ -182,7 +213,11 @@ def _build_batch(msas, loci, options, backend, out: Dict[str, dict]):
                 logger.warning(f"Skipping building PRG for {loci[i]}. Error: {res.error}")
                 continue
             prg, _, _ = build_prg(eng2, res)
-            emit(loci[i], msas[i], prg, lambda b, res=res, i=i: materialise(eng2, res, msas[i], b, None))
+            builder = None
+            if ot.prg:
+                builder = new_builder(loci[i], lambda b, res=res, i=i: materialise(eng2, res, msas[i], b, None))
+                assert builder.build_prg() == prg          # fills prg_index / site_num as the reference's build_prg() does
+            out[loci[i]] = locus_record(loci[i], prg, builder, ot)
 
 
 def _build_part(job):
@@ -194,7 +229,7 @@ def _build_part(job):
 
 def split_for_workers(files: List[Path], n: int) -> List[List[Path]]:
     """Size-balanced split of a rank's files over its host worker processes (same greedy rule as shard_files)."""
-    return [p for p in (shard_files(files, w, n) for w in range(n)) if p]
+    return [p for p in balanced_parts(files, n) if p]
 
 
 def _write_one(all_loci: Dict[str, dict], kind: str, output_prefix: str):

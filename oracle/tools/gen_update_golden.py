@@ -104,6 +104,45 @@ def check_against_truth(case, got):
     return sorted(truth)
 
 
+def run_case(spec, tmp, rec_dir, align_calls):
+    case, base, L, threshold, otype = spec
+    for f in rec_dir.iterdir():
+        f.unlink()
+    del align_calls[:]
+    base_path = DATA / base
+    files = sorted(base_path.iterdir()) if base_path.is_dir() else [base_path]
+    base_prefix = str(tmp / case / "base" / "base")
+    from_msa.run(Namespace(input=str(base_path), suffix="", output_prefix=base_prefix, alignment_format="fasta",
+                           log=None, max_nesting=5, min_match_length=L, output_type=output_type.OutputType("a"),
+                           force=True, threads=1, verbose=False))
+    upd_prefix = str(tmp / case / "out" / case)
+    denovo = DATA / case / "denovo_paths.txt"
+    update.run(Namespace(denovo_paths=str(denovo), update_DS=Path(base_prefix + ".update_DS.zip"),
+                         output_prefix=upd_prefix, long_deletion_threshold=threshold, log=None,
+                         output_type=output_type.OutputType(otype), force=True, threads=1, verbose=False))
+    got = outputs_of(upd_prefix)
+    checked = check_against_truth(case, got)
+    loci = {}
+    if otype in ("a", "p"):
+        db = PrgBuilderZipDatabase(Path(upd_prefix + ".update_DS.zip"))
+        db.load()
+        for locus in db.get_loci_names():
+            b = db.get_PrgBuilder(locus)
+            prg = b.build_prg()
+            loci[locus] = dict(prg=prg, tree=tree_dump(b.root), next_node_id=b.next_node_id, site_num=b.site_num,
+                               prg_index=sorted([s, e, n.node_id] for (s, e), n in b.prg_index.items()))
+        db.close()
+    files_expect = {}
+    for k, v in got.items():
+        files_expect[k] = {m: sha(x) for m, x in v.items()} if isinstance(v, dict) else sha(v)
+    replay = [json.load(open(rec_dir / f)) for f in sorted(os.listdir(rec_dir))]
+    return dict(case=case, N=5, L=L, long_deletion_threshold=threshold, output_type=otype,
+                      inputs=[dict(name=f.name, fasta=f.read_text()) for f in files],
+                      denovo_paths=denovo.read_text(), aligner_replay=replay, align_calls=list(align_calls),
+                      expect=dict(files_sha256=files_expect, prg_fa=got.get(".prg.fa", b"").decode(), loci=loci),
+                      checked_against_truth=checked)
+
+
 def main():
     for a, b, want in ALIGN_KNOWN:          # tests/utils/test_seq_utils.py::TestAlign
         assert align(a, b) == want, (a, b, align(a, b))
@@ -135,44 +174,17 @@ def main():
         return res
 
     dv.align = recording_align
+    import multiprocessing as mp
     cases = []
-    for case, base, L, threshold, otype in CASES:
-        for f in rec_dir.iterdir():
-            f.unlink()
-        del align_calls[:]
-        base_path = DATA / base
-        files = sorted(base_path.iterdir()) if base_path.is_dir() else [base_path]
-        base_prefix = str(tmp / case / "base" / "base")
-        from_msa.run(Namespace(input=str(base_path), suffix="", output_prefix=base_prefix, alignment_format="fasta",
-                               log=None, max_nesting=5, min_match_length=L, output_type=output_type.OutputType("a"),
-                               force=True, threads=1, verbose=False))
-        upd_prefix = str(tmp / case / "out" / case)
-        denovo = DATA / case / "denovo_paths.txt"
-        update.run(Namespace(denovo_paths=str(denovo), update_DS=Path(base_prefix + ".update_DS.zip"),
-                             output_prefix=upd_prefix, long_deletion_threshold=threshold, log=None,
-                             output_type=output_type.OutputType(otype), force=True, threads=1, verbose=False))
-        got = outputs_of(upd_prefix)
-        checked = check_against_truth(case, got)
-        loci = {}
-        if otype in ("a", "p"):
-            db = PrgBuilderZipDatabase(Path(upd_prefix + ".update_DS.zip"))
-            db.load()
-            for locus in db.get_loci_names():
-                b = db.get_PrgBuilder(locus)
-                prg = b.build_prg()
-                loci[locus] = dict(prg=prg, tree=tree_dump(b.root), next_node_id=b.next_node_id, site_num=b.site_num,
-                                   prg_index=sorted([s, e, n.node_id] for (s, e), n in b.prg_index.items()))
-            db.close()
-        files_expect = {}
-        for k, v in got.items():
-            files_expect[k] = {m: sha(x) for m, x in v.items()} if isinstance(v, dict) else sha(v)
-        replay = [json.load(open(rec_dir / f)) for f in sorted(os.listdir(rec_dir))]
-        cases.append(dict(case=case, N=5, L=L, long_deletion_threshold=threshold, output_type=otype,
-                          inputs=[dict(name=f.name, fasta=f.read_text()) for f in files],
-                          denovo_paths=denovo.read_text(), aligner_replay=replay, align_calls=list(align_calls),
-                          expect=dict(files_sha256=files_expect, prg_fa=got.get(".prg.fa", b"").decode(), loci=loci),
-                          checked_against_truth=checked))
-        print(case, "ok:", checked, "| mafft calls", len(replay), "| align calls", len(align_calls), "| loci", len(loci))
+    for spec in CASES:          # one forked child per case: the reference keeps its aligner and variants in a process-wide
+        recv, send = mp.Pipe(False)   # singleton (update_shared_data.py), which is why its own tests run forked
+        child = mp.get_context("fork").Process(target=lambda: send.send(run_case(spec, tmp, rec_dir, align_calls)))
+        child.start()
+        rec = recv.recv()
+        child.join()
+        cases.append(rec)
+        print(rec["case"], "ok:", rec["checked_against_truth"], "| mafft calls", len(rec["aligner_replay"]), "| align calls",
+              len(rec["align_calls"]), "| loci", len(rec["expect"]["loci"]))
     meta = dict(reference="iqbal-lab-org/make_prg v0.5.0 (unmodified, /root/reference, oracle/refshim)",
                 mafft="bundled v7.490 (make_prg/utils/mafft-linux64), --auto --quiet --thread 1 --add",
                 pinned=dict(n_init=10, OMP_NUM_THREADS=1, OPENBLAS_CORETYPE=rb.PINNED_CORETYPE),

@@ -53,6 +53,11 @@ def test_directory_of_alignments(tmp_path, golden_integration, monkeypatch):
     assert db.get_loci_names() == sorted(expect)
     for l in expect:
         b = db.get_PrgBuilder(l)
+        # the freshly loaded pickle already carries what the reference serialises after build_prg(): update needs it
+        assert sorted([s, e, n.node_id] for (s, e), n in b.prg_index.items()) == expect[l]["prg_index"]
+        assert b.site_num == expect[l]["site_num"] and b.next_node_id == expect[l]["next_node_id"]
+        assert all(set(k for k, n in b.prg_index.items() if n is leaf) == leaf.indexed_PRG_intervals
+                   for leaf in set(b.prg_index.values()))
         assert b.build_prg() == expect[l]["prg"] and b.next_node_id == expect[l]["next_node_id"]
     db.close()
     with pytest.raises(RuntimeError):
