@@ -186,6 +186,18 @@ int mprg_leaf_jobs(const int64_t *leaves, int64_t n_leaves, const int32_t *rowid
  * the host). */
 int mprg_emit_alleles(const uint8_t *arena, const int64_t *jobs, int64_t n_jobs, uint8_t *out, void *stream);
 
+/* (f)-1 output encoders, HOST functions (host pointers), one pass over a PRG string as PrgBuilder emits it.
+ * reference make_prg/utils/prg_encoder.py:44-91 and make_prg/utils/gfa.py:16-109.
+ * mprg_prg_encode_host: out[n] receives the uint32 stream (A C G T -> 1 2 3 4, markers as integers, the closing
+ *   occurrence of an odd site marker as the even one); returns the count.
+ * mprg_gfa_text_host: out[out_cap] receives the GFA1 text; returns its length, or MPRG_OUT_TOO_SMALL (-4): retry with a
+ *   bigger buffer (256 + 48 n always suffices; 4096 + 3 n does for pan-genome PRGs).
+ * Both return MPRG_NOT_PLAIN_STRING (-3) for anything PrgBuilder would not emit (the caller then uses the
+ * reference-shaped slow path, which owns the reference's errors and its `str(site) in prg` substring test). */
+enum { MPRG_NOT_PLAIN_STRING = -3, MPRG_OUT_TOO_SMALL = -4 };
+long long mprg_prg_encode_host(const char *prg, long long n, uint32_t *out);
+long long mprg_gfa_text_host(const char *prg, long long n, char *out, long long out_cap);
+
 #ifdef __cplusplus
 }
 #endif

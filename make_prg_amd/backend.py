@@ -39,6 +39,8 @@ SIGNATURES = {
     "mprg_leaf_jobs": (c_int, [c_void_p, c_int64] + [c_void_p] * 6),
     "mprg_emit_alleles": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mprg_random_sample_host": (None, [c_uint32, c_int, c_void_p]),
+    "mprg_prg_encode_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p]),
+    "mprg_gfa_text_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong]),
 }
 
 

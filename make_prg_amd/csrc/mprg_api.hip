@@ -13,6 +13,7 @@
 #include "k_kmeans_lds.inc"
 #include "k_cluster.inc"
 #include "k_emit.inc"
+#include "host_encoders.inc"
 
 static thread_local char g_err[512] = "";
 static int fail(const char *what) { snprintf(g_err, sizeof g_err, "%s", what); return -1; }

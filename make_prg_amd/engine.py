@@ -321,7 +321,8 @@ class BatchEngine:
         d_sp, d_wc, d_wr = be.upload(act_tab), be.upload(wc), be.upload(wr)
         be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp), nA, k,
                 be.ptr(d_dor), be.ptr(d_labels) if k > 1 else None, be.ptr(d_assign) if (k > 1 and d_assign is not None) else None,
-                be.ptr(d_wc), len(wc), be.ptr(d_wr), len(wr), be.ptr(d_scratch), be.ptr(d_further), be.stream)
+                be.ptr(d_wc), len(wc), be.ptr(d_wr), len(wr), be.ptr(d_scratch), be.ptr(d_further), be.stream,
+                work=float((sub[views, 5] * sub[views, 7]).sum()))      # the members' cells, read once per evaluated k
         self.counters["launches"] += 2
         return be.download(d_further, np.int32, nA).astype(bool)
 

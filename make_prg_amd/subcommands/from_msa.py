@@ -145,7 +145,7 @@ def locus_record(locus: str, prg: str, builder, output_type) -> dict:
         arr = enc.encode_array(prg)
         rec["bin"] = (arr if arr is not None else np.asarray(enc.encode(prg))).astype("<u4").tobytes()
     if output_type.gfa:
-        rec["gfa"] = GFA_Output.gfa_text(prg).encode()
+        rec["gfa"] = GFA_Output.gfa_bytes(prg)
     return rec
 
 

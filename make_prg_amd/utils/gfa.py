@@ -61,12 +61,23 @@ class GFA_Output:
 
     @staticmethod
     def gfa_text(prg_string) -> str:
+        from . import native
+        fast = native.gfa_text(prg_string)               # libmprg's one-pass host builder (same procedure, C)
+        if fast is not None:
+            return fast.decode("ascii")
         fast = gfa_text_single_pass(prg_string)
         if fast is not None:
             return fast
         g = GFA_Output(GFA_HEADER)
         g.build_gfa_string(prg_string=prg_string)
         return g.gfa_string
+
+    @staticmethod
+    def gfa_bytes(prg_string) -> bytes:
+        """The same text as bytes (what the containers store), without a decode/encode round trip."""
+        from . import native
+        fast = native.gfa_text(prg_string)
+        return fast if fast is not None else GFA_Output.gfa_text(prg_string).encode()
 
     @staticmethod
     def write_gfa(prefix, prg_string):

@@ -51,6 +51,13 @@ class PrgEncoder:
         seen more than twice, or an encoder that already holds marker counts from an earlier call."""
         if self._site_entry_markers:
             return None
+        if self.encoding is PrgEncoder.encoding:          # the default alphabet: libmprg's one-pass host encoder
+            from . import native
+            arr = native.prg_encode(prg)
+            if arr is not None:
+                odd = arr[(arr > 4) & (arr % 2 == 1)]
+                self._site_entry_markers = {int(v): 2 for v in np.unique(odd)} if len(odd) else {}
+                return arr
         try:
             b = np.frombuffer(prg.encode("ascii"), dtype=np.uint8)
         except UnicodeEncodeError:

@@ -34,3 +34,50 @@ def test_errors_come_from_the_unit_path():
     assert enc.encode(" 5 A 6 C 5 ") == [5, 1, 6, 2, 6]
     with pytest.raises(ValueError):                                             # marker counts persist in the encoder
         enc.encode(" 5 A")
+
+
+# ---- libmprg's one-pass host encoders (include/mprg.h: mprg_prg_encode_host, mprg_gfa_text_host)
+@pytest.fixture(scope="module")
+def native_lib():
+    """The emulation build exports the same host functions as the HIP build (same sources)."""
+    import ctypes
+    from make_prg_amd.backend import bind
+    from make_prg_amd.utils import native
+    from tests.emu.backend import build_emu
+    native.set_library(bind(ctypes.CDLL(build_emu())))
+    yield native
+    native.set_library(None)
+    native._tried = False
+
+
+def test_native_encoders_on_goldens(native_lib, golden_integration, golden_synthetic):
+    import oracle.from_msa_oracle as orc
+    from make_prg_amd.utils.gfa import GFA_Output, gfa_text_single_pass
+    prgs = [l["expect"]["prg"] for c in golden_integration["cases"] for l in c["loci"] if "prg" in l.get("expect", {})]
+    prgs += [l["expect"]["prg"] for l in golden_synthetic["loci"] if "prg" in l.get("expect", {})]
+    n_gfa = 0
+    for prg in prgs:
+        arr = native_lib.prg_encode(prg)
+        assert arr is not None and arr.tolist() == PrgEncoder()._encode_units(prg)
+        want = orc.gfa_text(prg)
+        assert gfa_text_single_pass(prg) == want                   # the Python single pass
+        got = native_lib.gfa_text(prg)
+        assert got is not None and got.decode() == want            # the C single pass
+        assert GFA_Output.gfa_text(prg) == want and GFA_Output.gfa_bytes(prg) == want.encode()
+        n_gfa += 1
+    assert n_gfa > 40
+
+
+def test_native_encoders_leave_odd_strings_to_the_reference_shaped_path(native_lib):
+    from make_prg_amd.utils.gfa import GFA_Output
+    for text in (" 5 A 6 C 5  5 A 6 T 5 ", "AC5G", "A 7 C 8 G 7 T", "A 5 C 6 G", "AC 5 G 5 T"):
+        assert native_lib.gfa_text(text) is None
+    for text in (" 5 A 6 C 5  5 A 6 T 5 ", "AC5G", "AXG"):
+        assert native_lib.prg_encode(text) is None
+    with pytest.raises(ValueError):
+        PrgEncoder().encode(" 5 A 6 C 5  5 A 6 T 5 ")
+    with pytest.raises(AssertionError):                            # the reference's own assertion (utils/gfa.py:49-52)
+        GFA_Output.gfa_text("A 5 C 6 G")
+    # tiny marker-dense strings need more than 3 bytes of GFA per byte of PRG: the wrapper retries with the bound
+    prg = "A 5  6  6  5 " * 1
+    assert native_lib.gfa_text(prg).decode() == GFA_Output.gfa_text(prg)

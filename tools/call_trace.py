@@ -9,7 +9,7 @@ import make_prg_amd.forest as F
 
 name = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-msas = make_batch(list(range(n)), 16)
+msas = make_batch(list(range(n)), 16)[1]
 be = HipBackend(0)
 eng = F.ForestEngine(be, 5, 7)
 eng.load(msas)

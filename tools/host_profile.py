@@ -9,7 +9,7 @@ from make_prg_amd.backend import HipBackend
 from make_prg_amd.forest import ForestEngine
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-msas = make_batch(list(range(n)), 16)
+msas = make_batch(list(range(n)), 16)[1]
 be = HipBackend(0)
 eng = ForestEngine(be, 5, 7)
 eng.load(msas)

@@ -8,7 +8,7 @@ from make_prg_amd.backend import HipBackend
 import make_prg_amd.forest as F
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-msas = make_batch(list(range(n)), 16)
+msas = make_batch(list(range(n)), 16)[1]
 be = HipBackend(0)
 eng = F.ForestEngine(be, 5, 7)
 eng.load(msas)

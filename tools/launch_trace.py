@@ -9,7 +9,7 @@ from make_prg_amd.backend import HipBackend
 import make_prg_amd.forest as F
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-msas = make_batch(list(range(n)), 16)
+msas = make_batch(list(range(n)), 16)[1]
 be = HipBackend(0)
 for rep in range(2):
     eng = F.ForestEngine(be, 5, 7)

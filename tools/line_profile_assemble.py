@@ -10,7 +10,7 @@ import make_prg_amd.forest as F
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 fname = sys.argv[2] if len(sys.argv) > 2 else "assemble_prgs"
-msas = make_batch(list(range(n)), 16)
+msas = make_batch(list(range(n)), 16)[1]
 be = HipBackend(0)
 eng = F.ForestEngine(be, 5, 7)
 eng.load(msas)

@@ -12,7 +12,7 @@ def worker(wi, W, batch, T, steps, bar, q):
     from concurrent.futures import ThreadPoolExecutor
     from make_prg_amd.backend import HipBackend
     from make_prg_amd.forest import ForestEngine
-    msas = make_batch(list(range(wi, batch, W)), 1)
+    msas = make_batch(list(range(wi, batch, W)), 1)[1]
     bes = [HipBackend(0, own_stream=True) for _ in range(T)]
     engs = [ForestEngine(b, 5, 7) for b in bes]
     for i, (e, b) in enumerate(zip(engs, bes)):

@@ -6,7 +6,7 @@ from bench import make_batch
 from make_prg_amd.backend import HipBackend
 import make_prg_amd.forest as F
 lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "make_prg_amd", "_lib", "libmprg_hip_timing.so")
-msas = make_batch(list(range(2048)), 16)
+msas = make_batch(list(range(2048)), 16)[1]
 be = HipBackend(0, lib_path=lib)
 be.lib.mprg_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int]
 eng = F.ForestEngine(be, 5, 7)
