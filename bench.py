@@ -49,7 +49,7 @@ def _text(seed):
 def _gen(seed):
     from make_prg_amd.msa import load_alignment_text
     text = _text(seed)
-    return text, load_alignment_text(text)
+    return text, load_alignment_text(text, defer_n=True)
 
 
 def _oracle_one(seed):
@@ -134,27 +134,32 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1):
         def end_to_end():
             """FASTA text -> PRG, .bin and .gfa bytes, nothing resident beforehand (a fresh engine; stream 0)."""
             from make_prg_amd.msa import load_alignment_text
+            from make_prg_amd.utils import native
             from make_prg_amd.utils.gfa import GFA_Output
             from make_prg_amd.utils.prg_encoder import PrgEncoder
             t0 = time.perf_counter()
-            parsed = [load_alignment_text(t) for t in texts]
+            parsed = [load_alignment_text(t, defer_n=True) for t in texts]
             t1 = time.perf_counter()
             with bes[0].on_stream():
                 eng = ForestEngine(bes[0], max_nesting=5, min_match_length=7)
                 eng.load(parsed)
                 t2 = time.perf_counter()
                 eng.run_forest()
-                prgs = eng.assemble_prgs()
+                prgs = eng.assemble_prgs(as_bytes=True)
                 bes[0].synchronize()
             t3 = time.perf_counter()
             n_bytes = 0
             for p in prgs:
                 if p is None:
                     continue
-                enc = PrgEncoder()
-                arr = enc.encode_array(p)
-                n_bytes += len((arr if arr is not None else np.asarray(enc.encode(p))).astype("<u4").tobytes())
-                n_bytes += len(GFA_Output.gfa_text(p))
+                b = bytes(p)
+                arr = native.prg_encode(b)                      # libmprg's one-pass host encoders; the reference-shaped
+                if arr is None:                                 # Python forms take over for strings they do not cover
+                    arr = np.asarray(PrgEncoder().encode(b.decode()), dtype="<u4")
+                g = native.gfa_text(b)
+                if g is None:
+                    g = GFA_Output.gfa_text(b.decode()).encode()
+                n_bytes += arr.nbytes + len(g)
             t4 = time.perf_counter()
             return dict(n=sum(p is not None for p in prgs), parse_s=t1 - t0, encode_upload_s=t2 - t1, build_s=t3 - t2,
                         encoders_s=t4 - t3, out_bytes=n_bytes)

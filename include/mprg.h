@@ -47,6 +47,24 @@ const char *mprg_last_error(void);
 /* number of compute units of the current device (grid sizing); <0 on error */
 int mprg_device_cus(void);
 
+/* A0 on the device — utils/io_utils.py:17-49 (load_alignment_file) / SURVEY.md §8(f)-2, (f)-4.
+ * mprg_ingest: the batch's alignments as the parser produced them (`raw`: per alignment rows x columns ASCII bytes, no
+ * padding) -> the arena's row-major and transposed coded copies (layout above; padding cells = 15).  Lower case folds to
+ * upper case; a byte outside ACGT-RYKMSWN sets status[alignment] = 1 (the reference ends such a locus with
+ * SequenceCurationError); N is replaced by n_replacement[repl_off + column] (a cell code) where the table gives an offset.
+ * msa_table: n_msas x MPRG_I_FIELDS int64 {raw offset, rows, columns, row-major base, transposed base, pitchC, pitchS,
+ * replacement offset (-1: keep N), first tile}; an alignment owns ceil(rows/64) * ceil(columns/64) consecutive tiles,
+ * n_tiles in all.  arena_bytes of `arena` are initialised by the call.
+ * mprg_column_residue_counts: for the load-time majority consensus (utils/seq_utils.py:246-290): per column of the listed
+ * alignments the number of rows holding each of A C G T R Y K M S W and the first such row.  table: 4 int64 per alignment
+ * {raw offset, rows, columns, col_off}; work: n_work x 2 int32 {table row, 256-column tile}; out: 20 int32 per column at
+ * 20 * (col_off + c) = count[10], first_row[10] (0x7fffffff: absent).  The seeded random choice stays on the host. */
+enum { MPRG_I_FIELDS = 9 };
+int mprg_ingest(const uint8_t *raw, const int64_t *msa_table, int n_msas, int64_t n_tiles, const uint8_t *n_replacement,
+                uint8_t *arena, int64_t arena_bytes, int32_t *status, void *stream);
+int mprg_column_residue_counts(const uint8_t *raw, const int64_t *table, const int32_t *work, int n_work, int32_t *out,
+                               void *stream);
+
 /* A2 + A8 — utils/seq_utils.py:219-239 (get_consensus_from_MSA) and :193-216 (all-gap columns).
  * work: n_items x 3 int32 {view, first column of a 1024-column tile (relative to the view, multiple of 4 in
  * absolute arena columns), first row position of a row chunk}; rows_per_chunk rows per item.

@@ -21,6 +21,8 @@ SIGNATURES = {
     "mprg_version": (ctypes.c_char_p, []),
     "mprg_last_error": (ctypes.c_char_p, []),
     "mprg_device_cus": (c_int, []),
+    "mprg_ingest": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mprg_column_residue_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "mprg_column_masks": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p, c_void_p]),
     "mprg_partition": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 9 +
                        [c_void_p, c_int, c_void_p, c_int, c_void_p]),

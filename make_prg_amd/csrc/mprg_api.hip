@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "k_ingest.inc"
 #include "k_columns.inc"
 #include "k_partition.inc"
 #include "k_rows.inc"
@@ -44,6 +45,22 @@ int mprg_device_cus(void) {
   int dev = 0; hipDeviceProp_t p;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return fail("no HIP device");
   return p.multiProcessorCount;
+}
+
+int mprg_ingest(const uint8_t *raw, const int64_t *msa_table, int n_msas, int64_t n_tiles, const uint8_t *n_replacement,
+                uint8_t *arena, int64_t arena_bytes, int32_t *status, void *stream) {
+  if (n_msas <= 0) return 0;
+  if (hipMemsetAsync(arena, 15, (size_t)arena_bytes, (hipStream_t)stream) != hipSuccess) return fail("memset");   // padding cells
+  if (hipMemsetAsync(status, 0, sizeof(int32_t) * n_msas, (hipStream_t)stream) != hipSuccess) return fail("memset");
+  if (n_tiles > 0) LAUNCH(k_ingest, n_tiles, 256, stream, raw, msa_table, n_msas, n_replacement, arena, status);
+  return check_launch("k_ingest");
+}
+
+int mprg_column_residue_counts(const uint8_t *raw, const int64_t *table, const int32_t *work, int n_work, int32_t *out,
+                               void *stream) {
+  if (n_work <= 0) return 0;
+  LAUNCH(k_column_residue_counts, n_work, 256, stream, raw, table, work, out);
+  return check_launch("k_column_residue_counts");
 }
 
 int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int32_t *work,

@@ -63,6 +63,25 @@ class LocusResult:
     stats: dict = field(default_factory=dict)
 
 
+class _LazyCodes:
+    """engine.codes[i]: the cell codes of alignment i on the HOST (the device has its own copies) — only tree dumps and the
+    rare leaves with ambiguity codes read them, so they are made on first use (bytes outside the alphabet read as 'A',
+    as on the device; such loci are dropped anyway)."""
+
+    def __init__(self, msas):
+        self._msas, self._cache = msas, {}
+
+    def __len__(self):
+        return len(self._msas)
+
+    def __getitem__(self, i):
+        i = int(i)
+        if i not in self._cache:
+            c = encode(self._msas[i].data) if self._msas[i].data.size else np.zeros((0, 0), np.uint8)
+            self._cache[i] = np.where(c == 255, 0, c).astype(np.uint8)
+        return self._cache[i]
+
+
 class BatchEngine:
     def __init__(self, backend, max_nesting: int = 5, min_match_length: int = 7):
         self.be = backend
@@ -74,39 +93,82 @@ class BatchEngine:
                                                launches=0)
 
     # ------------------------------------------------------------------------------------------------ packing
+    def _resolve_pending_n(self, msas: List[MSA]):
+        """Load-time majority consensus (utils/seq_utils.py:246-290) for the alignments that still hold N: the per-column
+        residue counts of ALL of them come from one device launch, the seeded random choice is the host's."""
+        from .msa import consensus_from_counts
+        idx = [i for i, m in enumerate(msas) if getattr(m, "pending_n", False)]
+        if not idx:
+            return
+        be = self.be
+        table = np.zeros((len(idx), 4), np.int64)
+        raw_off = col_off = 0
+        for j, i in enumerate(idx):
+            S, C = msas[i].data.shape
+            table[j] = (raw_off, S, C, col_off)
+            raw_off += S * C
+            col_off += C
+        raw = np.concatenate([np.ascontiguousarray(msas[i].data).reshape(-1) for i in idx])
+        cnt = (table[:, 2] + 255) // 256
+        work = np.empty((int(cnt.sum()), 2), np.int32)
+        work[:, 0] = np.repeat(np.arange(len(idx)), cnt)
+        work[:, 1] = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        d_raw, d_tab, d_work, d_out = be.upload(raw), be.upload(table), be.upload(work), be.empty(80 * max(col_off, 1))
+        be.call("mprg_column_residue_counts", be.ptr(d_raw), be.ptr(d_tab), be.ptr(d_work), len(work), be.ptr(d_out), be.stream,
+                work=float(raw.nbytes))
+        res = be.download(d_out, np.int32, 20 * col_off).reshape(col_off, 20).astype(np.int64)
+        for j, i in enumerate(idx):
+            m = msas[i]
+            co, C = int(table[j, 3]), int(table[j, 2])
+            is_n = m.data == ord("N")
+            last = int(np.nonzero(is_n.any(axis=0))[0].max())
+            cons = consensus_from_counts(m.data, res[co:co + C, :10], res[co:co + C, 10:], upto=last + 1)
+            if not m.data.flags.writeable:
+                m.data = m.data.copy()
+            m.data[is_n] = np.broadcast_to(cons, m.data.shape)[is_n]
+            m.pending_n = False
+
     def _pack(self, msas: List[MSA]):
-        """Encode every MSA and lay the batch out in one arena (row-major + transposed copy per MSA)."""
-        self.codes: List[np.ndarray] = []
+        """Lay the batch out in one arena (row-major + transposed coded copy per MSA): the host uploads each alignment
+        once, as the parser's ASCII matrix; mprg_ingest codes and transposes on the device."""
+        be = self.be
+        self._resolve_pending_n(msas)
+        self.codes = _LazyCodes(msas)
         self.bad: Dict[int, Exception] = {}
+        M = len(msas)
         metas = []
-        off = 0
+        itab = np.zeros((max(M, 1), 9), np.int64)
+        off = raw_off = tile = 0
         for i, m in enumerate(msas):
-            codes = encode(m.data)
-            if (codes == 255).any():
-                # any byte outside ACGT-RYKMSWN ends in SequenceCurationError in the reference (it reaches a
-                # SequenceExpander check in interval partitioning or leaf emission; utils/seq_utils.py:96-104)
-                r, c = np.argwhere(codes == 255)[0]
-                self.bad[i] = SequenceCurationError(
-                    f"A slice of a sequence has a disallowed base ({chr(m.data[r, c])!r} in {m.ids[r]}). Redo sequence curation.")
-                codes = np.where(codes == 255, 0, codes).astype(np.uint8)
-            self.codes.append(codes)
-            S, C = codes.shape
+            S, C = m.data.shape if m.data.ndim == 2 else (0, 0)
+            if S == 0:
+                C = 0
             pitchC, pitchS = _align(max(C, 1), 16), _align(max(S, 1), 16)
             rm = off
             off = _align(rm + S * pitchC, 256)
             cm = off
             off = _align(cm + C * pitchS, 256)
             metas.append((rm, cm, pitchC, pitchS, S, C))
-        arena = np.full(off + 256, 15, np.uint8)
-        for (rm, cm, pitchC, pitchS, S, C), codes in zip(metas, self.codes):
-            if S == 0 or C == 0:
-                continue
-            arena[rm:rm + S * pitchC].reshape(S, pitchC)[:, :C] = codes
-            arena[cm:cm + C * pitchS].reshape(C, pitchS)[:, :S] = codes.T
+            itab[i] = (raw_off, S, C, rm, cm, pitchC, pitchS, -1, tile)
+            raw_off += S * C
+            tile += ((S + 63) // 64) * ((C + 63) // 64)
         self.meta = metas
-        self.host_arena = arena
-        self.d_arena = self.be.upload(arena)
-        self.counters["arena_bytes"] = int(arena.nbytes)
+        parts = [np.ascontiguousarray(m.data).reshape(-1) for m in msas if m.data.size]
+        raw = np.concatenate(parts) if parts else np.zeros(1, np.uint8)
+        arena_bytes = off + 256
+        self.d_arena = be.empty(arena_bytes)
+        d_raw, d_itab, d_status = be.upload(raw), be.upload(itab), be.empty(4 * max(M, 1))
+        be.call("mprg_ingest", be.ptr(d_raw), be.ptr(d_itab), M, tile, None, be.ptr(self.d_arena), arena_bytes,
+                be.ptr(d_status), be.stream, work=3.0 * raw_off)
+        status = be.download(d_status, np.int32, M) if M else np.zeros(0, np.int32)
+        for i in np.nonzero(status)[0].tolist():
+            # any byte outside ACGT-RYKMSWN ends in SequenceCurationError in the reference (it reaches a
+            # SequenceExpander check in interval partitioning or leaf emission; utils/seq_utils.py:96-104)
+            m = msas[i]
+            r, c = np.argwhere(encode(m.data) == 255)[0]
+            self.bad[i] = SequenceCurationError(
+                f"A slice of a sequence has a disallowed base ({chr(m.data[r, c])!r} in {m.ids[r]}). Redo sequence curation.")
+        self.counters["arena_bytes"] = int(arena_bytes)
 
     # ------------------------------------------------------------------------------------------------ views
     def _view_table(self, nodes: List[NodeRec], idxs: List[int]):
@@ -202,7 +264,7 @@ class BatchEngine:
             if i in self.bad:
                 results[i].error = self.bad[i]
                 continue
-            S, C = self.codes[i].shape
+            S, C = self.meta[i][4], self.meta[i][5]
             nodes.append(NodeRec(i, -1, int(root_levels[i]), None, 0, C))
             results[i].root = len(nodes) - 1
             frontier.append(len(nodes) - 1)
@@ -705,7 +767,7 @@ def _one_view_engine(be, alignment: MSA, max_nesting=5, L=7) -> Tuple[BatchEngin
     eng.load([alignment])
     if 0 in eng.bad:
         raise eng.bad[0]
-    S, C = eng.codes[0].shape
+    S, C = eng.meta[0][4], eng.meta[0][5]
     return eng, [NodeRec(0, -1, 0, None, 0, C)]
 
 

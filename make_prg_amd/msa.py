@@ -73,6 +73,7 @@ def _fasta_title(rid: str, desc: str) -> str:
 
 class MSA:
     def __init__(self, records: Iterable[Record] = (), *, _data=None, _ids=None, _descs=None):
+        self.pending_n = False          # True: holds N that the batch engine still has to replace (load_alignment_text)
         if _data is not None:
             self.data, self.ids, self.descriptions = _data, list(_ids), list(_descs)
             return
@@ -228,28 +229,56 @@ def _majority_consensus_by_column(upper: np.ndarray, upto=None) -> np.ndarray:
     return out
 
 
-def load_alignment_text(text: str) -> MSA:
-    """utils/io_utils.py:17-49: parse, upper-case, overwrite every N with its column's majority-consensus base."""
+def consensus_from_counts(upper: np.ndarray, counts: np.ndarray, first: np.ndarray, upto: int) -> np.ndarray:
+    """The seeded choice of utils/seq_utils.py:246-290 given the per-column residue counts (10 residues "ACGTRYKMSW";
+    counts[c, q], first[c, q] = first row holding residue q or a huge value) — what mprg_column_residue_counts produces on
+    the device, or _residue_counts_host below.  One random.Random(sha256(rows)) draw per column 0..upto-1, in order."""
+    rng = random.Random()
+    rng.seed(hashlib.sha256(np.ascontiguousarray(upper).tobytes()).digest())
+    C = upper.shape[1]
+    out = np.full(C, ord("A"), np.uint8)
+    residues = "ACGTRYKMSW"
+    top = counts.max(axis=1) if counts.size else np.zeros(C, np.int64)
+    choice = rng.choice
+    for c in range(min(C, upto)):
+        if top[c] == 0:
+            out[c] = ord(choice("ACGT"))
+            continue
+        tied = np.nonzero(counts[c] == top[c])[0]
+        if len(tied) > 1:
+            tied = tied[np.argsort(first[c, tied], kind="stable")]
+        out[c] = ord(choice([residues[q] for q in tied]))
+    return out
+
+
+def load_alignment_text(text: str, defer_n: bool = False) -> MSA:
+    """utils/io_utils.py:17-49: parse, upper-case, overwrite every N with its column's majority-consensus base.
+    defer_n: leave the N in place and mark the alignment (`pending_n`): the batch engine then gets the column counts
+    from the device (mprg_column_residue_counts) for all such alignments of a batch at once."""
     msa = read_fasta_alignment(text)
     data = msa.data.copy()
     lower = (data >= ord("a")) & (data <= ord("z"))
     data[lower] -= 32
+    out = MSA(_data=data, _ids=msa.ids, _descs=msa.descriptions)
     is_n = data == ord("N")
     if is_n.any():          # the consensus is only ever used to overwrite N (io_utils.py:36-47): no N, no work
+        if defer_n:
+            out.pending_n = True
+            return out
         last = int(np.nonzero(is_n.any(axis=0))[0].max())
         cons = _majority_consensus(data, upto=last + 1)     # the RNG stream must still advance column by column
         data[is_n] = np.broadcast_to(cons, data.shape)[is_n]
-    return MSA(_data=data, _ids=msa.ids, _descs=msa.descriptions)
+    return out
 
 
-def load_alignment_file(msa_file, alignment_format: str = "fasta") -> MSA:
+def load_alignment_file(msa_file, alignment_format: str = "fasta", defer_n: bool = False) -> MSA:
     if alignment_format != "fasta":
         raise ValueError("only the fasta alignment format is supported by the MI355X path")
     if isinstance(msa_file, StringIO):
-        return load_alignment_text(msa_file.getvalue())
+        return load_alignment_text(msa_file.getvalue(), defer_n)
     path = str(msa_file)
     if path.endswith(".gz"):
         with gzip.open(path, "rt") as fh:
-            return load_alignment_text(fh.read())
+            return load_alignment_text(fh.read(), defer_n)
     with open(path) as fh:
-        return load_alignment_text(fh.read())
+        return load_alignment_text(fh.read(), defer_n)

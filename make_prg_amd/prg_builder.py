@@ -26,7 +26,7 @@ class PrgBuilder(object):
         if _root_factory is not None:                      # batched CLI path: tree already built on the device
             self.root = _root_factory(self)
         else:
-            alignment = load_alignment_file(str(msa_file), alignment_format)
+            alignment = load_alignment_file(str(msa_file), alignment_format, defer_n=True)   # resolved by the engine's load()
             self.root: RecursiveTreeNode = NodeFactory.build(alignment, self, None)
 
     @property

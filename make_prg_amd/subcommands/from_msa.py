@@ -93,7 +93,7 @@ def shard_files(files: List[Path], rank: int, world: int) -> List[Path]:
 def _load_one(args):
     path, fmt = args
     try:
-        return load_alignment_file(path, fmt)
+        return load_alignment_file(path, fmt, defer_n=True)      # N columns are counted on the device, batch-wise
     except ValueError as err:
         return err
 

@@ -32,7 +32,7 @@ ENGINE = "forest"          # which host the parity checks drive: "forest" (array
 
 
 def run_batch(backend, texts, N, L, engine=None):
-    msas = [load_alignment_text(t) for t in texts]
+    msas = [load_alignment_text(t, defer_n=True) for t in texts]     # N columns: counted on the device
     if (engine or ENGINE) == "nodes":
         eng = BatchEngine(backend, N, L)
         res = eng.build(msas)

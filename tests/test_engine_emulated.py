@@ -38,3 +38,26 @@ def test_speculative_k_rounds_give_the_same_trees(emu, golden_synthetic, monkeyp
     monkeypatch.setattr(ForestEngine, "k_slots", 3)
     assert pc.check_synthetic(emu, golden_synthetic, configs=("B",), limit=16) == 16
     assert pc.check_synthetic(emu, golden_synthetic, configs=("C",), limit=3) == 3
+
+
+def test_load_time_consensus_counts_from_the_device(emu):
+    """mprg_column_residue_counts + the host's seeded choice == the host-only majority consensus (reference
+    utils/seq_utils.py:246-290), on alignments with many N, ties, lower case, ambiguity codes and all-N columns."""
+    import numpy as np
+    from make_prg_amd.engine import BatchEngine
+    from make_prg_amd.msa import load_alignment_text
+    rng = np.random.default_rng(12)
+    texts = []
+    for t in range(60):
+        S, C = int(rng.integers(1, 40)), int(rng.integers(1, 300))
+        alphabet = np.frombuffer(b"ACGTacgtNNNn--RYKMSW" if t % 3 else b"ACGTNN-", np.uint8)
+        rows = alphabet[rng.integers(0, len(alphabet), (S, C))]
+        if t % 5 == 0:
+            rows[:, int(rng.integers(0, C))] = ord("N")                 # a column of nothing but N
+        texts.append("".join(f">r{i} d\n{bytes(r).decode()}\n" for i, r in enumerate(rows)))
+    want = [load_alignment_text(t) for t in texts]
+    got = [load_alignment_text(t, defer_n=True) for t in texts]
+    assert any(m.pending_n for m in got)
+    BatchEngine(emu, 5, 7).load(got)
+    for w, g in zip(want, got):
+        assert not g.pending_n and np.array_equal(w.data, g.data)
