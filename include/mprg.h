@@ -216,6 +216,15 @@ enum { MPRG_NOT_PLAIN_STRING = -3, MPRG_OUT_TOO_SMALL = -4 };
 long long mprg_prg_encode_host(const char *prg, long long n, uint32_t *out);
 long long mprg_gfa_text_host(const char *prg, long long n, char *out, long long out_cap);
 
+/* (f)-2 ingest, HOST functions: FASTA alignment text -> rows x columns matrix of upper-cased bytes, two passes.
+ * reference utils/io_utils.py:17-31 (AlignIO.read(handle, "fasta") + upper-casing).  mprg_fasta_scan_host counts the
+ * records and checks that all sequences have one length (0 ok, MPRG_NOT_PLAIN_STRING: bytes other than printable ASCII /
+ * tab / CR / LF — the caller's Python parser takes those —, MPRG_RAGGED_ALIGNMENT: lengths differ);
+ * mprg_fasta_fill_host writes matrix[r * seq_len + c] and, per record, the [start, end) offsets of its title in `text`. */
+enum { MPRG_RAGGED_ALIGNMENT = -5 };
+long long mprg_fasta_scan_host(const char *text, long long n, long long *n_records, long long *seq_len);
+long long mprg_fasta_fill_host(const char *text, long long n, uint8_t *matrix, long long seq_len, long long *title_spans);
+
 #ifdef __cplusplus
 }
 #endif

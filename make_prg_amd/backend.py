@@ -42,6 +42,8 @@ SIGNATURES = {
     "mprg_emit_alleles": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mprg_random_sample_host": (None, [c_uint32, c_int, c_void_p]),
     "mprg_prg_encode_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p]),
+    "mprg_fasta_scan_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
+    "mprg_fasta_fill_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_void_p]),
     "mprg_gfa_text_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong]),
 }
 

@@ -255,11 +255,23 @@ def load_alignment_text(text: str, defer_n: bool = False) -> MSA:
     """utils/io_utils.py:17-49: parse, upper-case, overwrite every N with its column's majority-consensus base.
     defer_n: leave the N in place and mark the alignment (`pending_n`): the batch engine then gets the column counts
     from the device (mprg_column_residue_counts) for all such alignments of a batch at once."""
-    msa = read_fasta_alignment(text)
-    data = msa.data.copy()
-    lower = (data >= ord("a")) & (data <= ord("z"))
-    data[lower] -= 32
-    out = MSA(_data=data, _ids=msa.ids, _descs=msa.descriptions)
+    from .utils import native
+    parsed = native.parse_fasta(text)          # libmprg's two-pass host parser (plain ASCII text; else the Python one)
+    if parsed is not None:
+        data, titles = parsed
+        if len(titles) == 0:
+            raise ValueError("No records found in handle")
+        ids = []
+        for title in titles:
+            words = title.split(None, 1)
+            ids.append(words[0] if words else "")
+        out = MSA(_data=data, _ids=ids, _descs=titles)
+    else:
+        msa = read_fasta_alignment(text)
+        data = msa.data.copy()
+        lower = (data >= ord("a")) & (data <= ord("z"))
+        data[lower] -= 32
+        out = MSA(_data=data, _ids=msa.ids, _descs=msa.descriptions)
     is_n = data == ord("N")
     if is_n.any():          # the consensus is only ever used to overwrite N (io_utils.py:36-47): no N, no work
         if defer_n:

@@ -53,3 +53,24 @@ def gfa_text(prg) -> Optional[bytes]:
         if n != -4:                      # MPRG_OUT_TOO_SMALL: once more with the worst-case bound
             break
     return buf.raw[:n] if n >= 0 else None
+
+
+def parse_fasta(text):
+    """(matrix uint8 [rows, columns] upper-cased, titles list) of a FASTA alignment, or None if the native parser does not
+    apply (library missing, or bytes it leaves to the Python parser).  Raises ValueError for sequences of unequal length."""
+    lib = library()
+    if lib is None:
+        return None
+    data = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+    n_rec, seq_len = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    rc = lib.mprg_fasta_scan_host(data, len(data), ctypes.byref(n_rec), ctypes.byref(seq_len))
+    if rc == -5:
+        raise ValueError("Sequences must all be the same length")
+    if rc != 0:
+        return None
+    S, L = n_rec.value, seq_len.value
+    matrix = np.empty((S, L), np.uint8)
+    spans = np.empty((max(S, 1), 2), np.int64)
+    lib.mprg_fasta_fill_host(data, len(data), matrix.ctypes.data, L, spans.ctypes.data)
+    titles = [data[a:b].decode("ascii") for a, b in spans[:S].tolist()]
+    return matrix, titles

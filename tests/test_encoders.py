@@ -81,3 +81,30 @@ def test_native_encoders_leave_odd_strings_to_the_reference_shaped_path(native_l
     # tiny marker-dense strings need more than 3 bytes of GFA per byte of PRG: the wrapper retries with the bound
     prg = "A 5  6  6  5 " * 1
     assert native_lib.gfa_text(prg).decode() == GFA_Output.gfa_text(prg)
+
+
+def test_native_fasta_parser_equals_the_python_parser(native_lib):
+    """mprg_fasta_scan_host / mprg_fasta_fill_host against read_fasta_alignment (the Bio.AlignIO-shaped parser) on wrapped
+    lines, CRLF, blanks inside sequences, lower case, text before the first record, empty input, ragged rows, and the
+    inputs the native parser hands back (form feed, old-Mac line ends, non-ASCII)."""
+    import numpy as np
+    from make_prg_amd.msa import load_alignment_text
+    from make_prg_amd.utils import native
+    lib = native._lib
+    cases = [">a desc here  \nACGT\nac gt\n>b\r\nAC\tGT\r\nACGT\r\n", "junk\n>x\nAC\n\n>y \nGT\n", ">only\n", "", "no records\n",
+             ">a\nACG\n>b\nAC\n", ">a\nAC\x0cGT\n>b\nACGT\n", ">é\nAC\n", ">a\rAC\r>b\rGT\r", ">a\nacgtn\n>b\nACGTN",
+             ">a\n\n\nAC\n>b\nA\nC", ">a  two words\t\nAC-N\n>a  two words\nRYKM"]
+    try:
+        for text in cases:
+            res = []
+            for use in (True, False):
+                native.set_library(lib if use else None)
+                try:
+                    m = load_alignment_text(text)
+                    res.append((m.data.tobytes(), m.data.shape, m.ids, m.descriptions))
+                except ValueError as e:
+                    res.append(("ValueError", str(e)))
+            assert res[0] == res[1], repr(text)
+        assert native.parse_fasta(cases[0]) is not None and native.parse_fasta(cases[6]) is None
+    finally:
+        native.set_library(lib)
