@@ -16,3 +16,7 @@ def get_backend():
         from .backend import HipBackend
         _backend = HipBackend()          # raises MprgError without libmprg_hip.so + a ROCm device: no fallback
     return _backend
+
+
+def backend_is_set() -> bool:
+    return _backend is not None

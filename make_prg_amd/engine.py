@@ -887,6 +887,32 @@ def _bm_cluster(self: BatchEngine, alignment: MSA, kmer_size: int):
     return clusters, None
 
 
+def _bm_not_one_reference_like(self: BatchEngine, clusters: List[List[str]]) -> List[bool]:
+    """cluster_sequences.py:100-111 for a list of clusters (each a list of equal-length gapped rows): True where some row
+    is further than the one-reference-like threshold from its cluster's majority string.  One alignment per cluster, all of
+    them through mprg_ungap_dedupe + mprg_cluster_further (k = 1) in one batch."""
+    be = self.be
+    msas = [MSA.from_strings(c) for c in clusters]
+    eng = BatchEngine(be, 1 << 30, 1)
+    eng.load(msas)
+    for i in eng.bad:
+        raise eng.bad[i]
+    nodes = [NodeRec(i, -1, 0, None, 0, eng.meta[i][5]) for i in range(len(msas))]
+    tab, rowidx, total_cols, total_rows = eng._view_table(nodes, list(range(len(nodes))))
+    d_rowidx = be.upload(rowidx)
+    sub = tab.copy()
+    usize = sub[:, 7] * ((sub[:, 5] + 15) // 16 * 16)
+    sub[:, 10] = np.cumsum(usize) - usize
+    d_sub = be.upload(sub)
+    dd = eng._dedupe(d_sub, d_rowidx, len(nodes), total_rows, int(usize.sum()), sub=sub)
+    sm = be.download(dd["summary"], np.int64, 8 * len(nodes)).reshape(len(nodes), 8)
+    act = np.zeros((len(nodes), PF), np.int64)
+    act[:, 0], act[:, 1] = np.arange(len(nodes)), sm[:, 2]
+    d_scratch, d_further = be.empty(12 * total_cols + 64), be.empty(4 * len(nodes))
+    return eng._cluster_further(d_sub, d_rowidx, sub, act, 1, dd["d_of_row"], None, None, d_scratch, d_further).tolist()
+
+
+BatchEngine.some_cluster_not_one_reference_like = _bm_not_one_reference_like
 BatchEngine.column_masks = _bm_column_masks
 BatchEngine.partition = _bm_partition
 BatchEngine.row_groups = _bm_row_groups

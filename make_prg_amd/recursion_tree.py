@@ -215,6 +215,53 @@ class NodeFactory:
             raise res.error
         return materialise(eng, res, alignment, prg_builder, parent_node)
 
+    # ---- the reference's private helpers, same names and results (reference :475-572); the batched build does not go
+    #      through them (one level of many alignments per launch), callers and the reference's unit tests do
+    @staticmethod
+    def _get_vertical_partition(alignment: MSA, min_match_length: int):
+        """(all intervals, match intervals) of the alignment's consensus — reference :500-513."""
+        from .from_msa.interval_partition import IntervalPartitioner
+        from .utils.seq_utils import get_consensus_from_MSA
+        match, _non_match, all_intervals = IntervalPartitioner(get_consensus_from_MSA(alignment), min_match_length,
+                                                               alignment).get_intervals()
+        return all_intervals, match
+
+    @staticmethod
+    def _is_multi_interval(all_intervals) -> bool:
+        return len(all_intervals) > 1
+
+    @staticmethod
+    def _is_single_match_interval(all_intervals, match_intervals) -> bool:
+        return len(all_intervals) == 1 and all_intervals[0] in match_intervals
+
+    @staticmethod
+    def _partition_alignment_into_interval_subalignments(alignment: MSA, all_intervals) -> SubMSAs:
+        return [alignment[:, interval.start:interval.stop + 1] for interval in all_intervals]
+
+    @staticmethod
+    def _alignment_has_issues(alignment: MSA) -> bool:
+        """Too few distinct sequences to cluster, or one sequence aligned in two ways — reference :475-494."""
+        from .utils.seq_utils import (get_number_of_unique_gapped_sequences, get_number_of_unique_ungapped_sequences)
+        n_ungapped = get_number_of_unique_ungapped_sequences(alignment)
+        return n_ungapped <= 2 or n_ungapped < get_number_of_unique_gapped_sequences(alignment)
+
+    @staticmethod
+    def _infer_if_we_should_cluster_further(alignment: MSA, clustering_result, nesting_level: int, max_nesting: int) -> bool:
+        """reference :538-556."""
+        if clustering_result.no_clustering or nesting_level + 1 >= max_nesting:
+            return False
+        return not NodeFactory._alignment_has_issues(alignment)
+
+    @staticmethod
+    def _get_sub_alignment_by_list_id(id_list, alignment: MSA) -> MSA:
+        wanted = set(id_list)
+        return MSA([record for record in alignment if record.id in wanted])
+
+    @staticmethod
+    def _get_subalignments_by_clustering(alignment: MSA, clustering_result) -> SubMSAs:
+        """One sub-alignment per cluster, rows in the alignment's order — reference :558-572."""
+        return [NodeFactory._get_sub_alignment_by_list_id(ids, alignment) for ids in clustering_result.clustered_ids]
+
     @staticmethod
     def build_many(jobs) -> list:
         """Batched re-entry: jobs = [(alignment, prg_builder, parent_node or None), ...] -> the sub-trees, in job order.

@@ -248,23 +248,89 @@ def _write_one(all_loci: Dict[str, dict], kind: str, output_prefix: str):
 
 
 def write_final_files(all_loci: Dict[str, dict], output_type, output_prefix: str, parallel: bool = False):
-    """reference utils/input_output_files.py:73-162.  parallel: one forked writer process per output file (the
-    containers are independent; only for a parent that has not initialised the GPU)."""
+    """reference utils/input_output_files.py:73-162.  parallel: one writer THREAD per output file — the containers are
+    independent and a stored (uncompressed) zip member is a CRC-32 plus a write, both of which release the GIL; threads
+    (not forked processes) so that a rank that has initialised the GPU can use them too."""
     kinds = (["fa", "pickle"] if output_type.prg else []) + (["bin"] if output_type.binary else []) + \
             (["gfa"] if output_type.gfa else [])
     if parallel and len(kinds) > 1 and len(all_loci) >= 256:
-        import multiprocessing as mp
-        ctx = mp.get_context("fork")
-        procs = [ctx.Process(target=_write_one, args=(all_loci, k, output_prefix)) for k in kinds]
-        for p in procs:
-            p.start()
-        for p in procs:
-            p.join()
-        if any(p.exitcode != 0 for p in procs):
-            raise RuntimeError("writing the output files failed")
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(len(kinds)) as pool:
+            list(pool.map(lambda k: _write_one(all_loci, k, output_prefix), kinds))
     else:
         for k in kinds:
             _write_one(all_loci, k, output_prefix)
+
+
+# ---- the job's single exchange (SURVEY.md §8e): every rank's per-locus output bytes to rank 0
+_FIELDS = ("prg", "pickle", "bin", "gfa")
+
+
+def pack_records(local: Dict[str, dict]) -> bytes:
+    """{locus: {prg (str), pickle / bin / gfa (bytes)}} -> one byte string: a JSON index (names, field lengths) then the
+    fields back to back.  No pickling of the dictionary: the payload of a 30 000-locus run is ~13 GB of bytes that are
+    only ever copied."""
+    import json
+    import struct
+    index, chunks = [], []
+    for locus in sorted(local):
+        rec = local[locus]
+        lens = []
+        for f in _FIELDS:
+            v = rec.get(f)
+            if v is None:
+                lens.append(-1)
+                continue
+            b = v.encode() if isinstance(v, str) else bytes(v)
+            lens.append(len(b))
+            chunks.append(b)
+        index.append([locus, lens])
+    head = json.dumps(index, separators=(",", ":")).encode()
+    return struct.pack("<Q", len(head)) + head + b"".join(chunks)
+
+
+def unpack_records(buf) -> Dict[str, dict]:
+    import json
+    import struct
+    mv = memoryview(buf)
+    (n,) = struct.unpack("<Q", mv[:8])
+    index = json.loads(bytes(mv[8:8 + n]))
+    pos = 8 + n
+    out: Dict[str, dict] = {}
+    for locus, lens in index:
+        rec = {}
+        for f, ln in zip(_FIELDS, lens):
+            if ln < 0:
+                continue
+            piece = bytes(mv[pos:pos + ln])
+            rec[f] = piece.decode() if f == "prg" else piece
+            pos += ln
+        out[locus] = rec
+    return out
+
+
+def gather_records(local: Dict[str, dict], dist, rank: int, world: int):
+    """all_gather of the ranks' byte counts, then ONE gather of the packed records, padded to the largest, as uint8 (RCCL
+    moves device tensors; gloo host tensors).  Returns the merged dictionary on rank 0, None elsewhere."""
+    import torch
+    on_device = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
+    payload = np.frombuffer(pack_records(local), dtype=np.uint8)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([payload.size], dtype=torch.int64, device=dev))
+    sizes = [int(t.item()) for t in sizes]
+    cap = max(max(sizes), 1)
+    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if payload.size:
+        mine[:payload.size] = torch.from_numpy(payload.copy()).to(dev)
+    parts = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, parts, dst=0)
+    if rank != 0:
+        return None
+    merged: Dict[str, dict] = {}
+    for t, n in zip(parts, sizes):
+        merged.update(unpack_records(t[:n].cpu().numpy().tobytes()))
+    return merged
 
 
 def run(cl_options, backend=None):
@@ -309,15 +375,11 @@ def _run(options, backend, pool, n_workers):
     logger.info(f"rank {rank}: {len(local)} of {len(mine)} loci built in {time.time() - t0:.1f}s ({n_workers} host workers)")
     t0 = time.time()
     if dist is not None:
-        gathered = [None] * world if rank == 0 else None
-        dist.gather_object(local, gathered, dst=0)          # the single exchange of the job
+        local = gather_records(local, dist, rank, world)    # the single exchange of the job
         if rank != 0:
             return
-        local = {}
-        for part in gathered:
-            local.update(part)
     if not local:
         logger.error("No PRGs were built, please check errors")
         return
-    write_final_files(local, options.output_type, options.output_prefix, parallel=pool is not None and dist is None)
+    write_final_files(local, options.output_type, options.output_prefix, parallel=True)
     logger.info(f"output files written in {time.time() - t0:.1f}s")

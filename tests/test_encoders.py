@@ -105,6 +105,7 @@ def test_native_fasta_parser_equals_the_python_parser(native_lib):
                 except ValueError as e:
                     res.append(("ValueError", str(e)))
             assert res[0] == res[1], repr(text)
+        native.set_library(lib)
         assert native.parse_fasta(cases[0]) is not None and native.parse_fasta(cases[6]) is None
     finally:
         native.set_library(lib)

@@ -1,0 +1,43 @@
+"""The parity-checked DEEP case on the MI355X: one hierarchical alignment of 2 000 x 4 000 (-N 7 -L 7) whose recursion
+tree has ~10^4 nodes down to nesting level 6 and ~4 000 KMeans fits of up to 817 sequences x 16 354 k-mers — BASELINE.json
+config D's stress (recursion depth, clustering problems far beyond a CU's LDS, the global-memory KMeans kernels) at a size
+the oracle finishes in minutes.  Everything is compared with the oracle's fixture (tests/golden/ddeep.json, made by
+oracle/tools/gen_ddeep_golden.py): PRG, the product's .bin and .gfa encoders, the full recursion tree, prg_index, counters."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import parity_common as pc
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_deep_hierarchical_alignment_against_the_oracle_fixture():
+    from make_prg_amd.backend import HipBackend
+    from make_prg_amd.forest import ForestEngine
+    from make_prg_amd.msa import load_alignment_text
+    from make_prg_amd.utils.gfa import GFA_Output
+    from make_prg_amd.utils.synthetic import synth_deep_fasta
+    with open(os.path.join(HERE, "golden", "ddeep.json")) as fh:
+        g = json.load(fh)
+    text = synth_deep_fasta(g["seed"], g["S"], g["C"])
+    assert pc.sha(text) == g["fasta_sha256"], "the generator changed under the fixture"
+    msa = load_alignment_text(text)
+    eng = ForestEngine(HipBackend(0), g["N"], g["L"])
+    eng.load([msa])
+    eng.run_forest()
+    prg = eng.assemble_prgs(want_index=True)[0]
+    e = g["expect"]
+    assert prg is not None and len(prg) == e["prg_len"] and pc.sha(prg) == e["prg_sha256"]
+    assert int(eng.counters["fits"]) == g["kmeans_fits"]
+    assert pc.sha(pc.product_bin_bytes(prg)) == e["bin_sha256"]
+    assert pc.sha(GFA_Output.gfa_text(prg)) == e["gfa_sha256"]
+    tree = eng.tree_dump(0, msa.ids)
+    assert len(tree) == g["nodes"] == e["next_node_id"]
+    assert max(n["level"] for n in tree) == max(int(k) for k in g["levels"])
+    assert pc.sha(tree) == e["tree_sha256"], "recursion tree differs from the oracle's"
+    assert pc.sha(eng.prg_index(0)) == e["prg_index_sha256"]
+    assert 5 + 2 * int(eng.site_count[0]) == e["site_num"]

@@ -112,3 +112,15 @@ def test_batched_reentry_below_existing_nodes_on_gpu(hip):
             assert b.next_node_id == c["jobs"][-1]["next_node_id"]
     finally:
         device.set_backend(None)
+
+
+def test_exported_helper_functions_on_gpu(hip):
+    """cluster_sequences' exported helpers and NodeFactory's private helpers against the real reference's answers, the
+    one-reference-like test on the HIP kernel of the recursion (tests/golden/helpers.json.gz)."""
+    from make_prg_amd import device
+    from tests.test_helpers_api import check_all, load
+    device.set_backend(hip)
+    try:
+        assert check_all(load()) > 300
+    finally:
+        device.set_backend(None)
