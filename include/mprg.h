@@ -97,9 +97,9 @@ int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *ro
 
 /* A9a/A13/A16 — from_msa/cluster_sequences.py:220-233 (ungap, group identical rows in first-appearance order),
  * utils/seq_utils.py:58-70 (unique gapped / ungapped counts).  Ungap + hash: one workgroup per (view, 256-row chunk)
- * — work_rows: n x 2 int32 {view, chunk} —; grouping: one workgroup per view.
- * views[AUX0] = byte offset of this view's region in `ucodes` (n_cols * n_rows_pad bytes, n_rows_pad =
- * round_up(n_rows,16)); ungapped codes are stored transposed: character j of row position i at j*n_rows_pad + i.
+ * — work_rows: n x 2 int32 {view, chunk} —, one wavefront per row; grouping: one workgroup per view.
+ * views[AUX0] = byte offset (a multiple of 16) of this view's region in `ucodes`: n_rows * upitch bytes, upitch =
+ * round_up(n_cols, 16); ungapped codes are stored ROW-MAJOR: character j of row position i at i*upitch + j.
  * per row (at row_off): ulen, rep_u (smallest row position with identical ungapped content), rep_g (same for gapped
  * content), d_of_row (index of the row's sequence among the distinct sequences of length >= kmer_size, first-appearance
  * order; -1 if shorter), s_of_row (index among the distinct shorter sequences; -1 if long).

@@ -412,8 +412,7 @@ class BatchEngine:
         sel = cands + leaves
         # sub-table of the selected views with their own row offsets and ucodes regions
         sub = tab[sel].copy()
-        pad_rows = (sub[:, 5] + 15) // 16 * 16
-        usize = sub[:, 7] * pad_rows
+        usize = sub[:, 5] * ((sub[:, 7] + 15) // 16 * 16)          # ungapped rows, row-major, 16-byte pitch
         sub[:, 10] = np.cumsum(usize) - usize
         sub[:, 9] = np.cumsum(sub[:, 5]) - sub[:, 5]
         sub[:, 8] = np.cumsum(sub[:, 7]) - sub[:, 7]
@@ -816,7 +815,7 @@ def _bm_row_groups(self: BatchEngine, alignment: MSA):
     S = int(tab[0, 5])
     tab[0, 10] = 0
     d_sub = be.upload(tab)
-    dd = eng._dedupe(d_sub, d_rowidx, 1, S, int(tab[0, 7]) * ((S + 15) // 16 * 16), sub=tab)
+    dd = eng._dedupe(d_sub, d_rowidx, 1, S, S * ((int(tab[0, 7]) + 15) // 16 * 16), sub=tab)
     ru, rg = be.download(dd["rep_u"], np.int32, S), be.download(dd["rep_g"], np.int32, S)
     ulen = be.download(dd["ulen"], np.int32, S)
     ar = np.arange(S)
@@ -834,7 +833,7 @@ def _bm_cluster(self: BatchEngine, alignment: MSA, kmer_size: int):
     sub = tab.copy()
     sub[0, 10] = 0
     d_sub = be.upload(sub)
-    dd = eng._dedupe(d_sub, d_rowidx, 1, S, int(sub[0, 7]) * ((S + 15) // 16 * 16), sub=sub)
+    dd = eng._dedupe(d_sub, d_rowidx, 1, S, S * ((int(sub[0, 7]) + 15) // 16 * 16), sub=sub)
     d_ucodes, d_ulen = dd["ucodes"], dd["ulen"]
     ul, ru = be.download(dd["ulen"], np.int32, S), be.download(dd["rep_u"], np.int32, S)
     is_rep = ru == np.arange(S)
@@ -901,7 +900,7 @@ def _bm_not_one_reference_like(self: BatchEngine, clusters: List[List[str]]) -> 
     tab, rowidx, total_cols, total_rows = eng._view_table(nodes, list(range(len(nodes))))
     d_rowidx = be.upload(rowidx)
     sub = tab.copy()
-    usize = sub[:, 7] * ((sub[:, 5] + 15) // 16 * 16)
+    usize = sub[:, 5] * ((sub[:, 7] + 15) // 16 * 16)
     sub[:, 10] = np.cumsum(usize) - usize
     d_sub = be.upload(sub)
     dd = eng._dedupe(d_sub, d_rowidx, len(nodes), total_rows, int(usize.sum()), sub=sub)

@@ -262,7 +262,7 @@ class ForestEngine(BatchEngine):
         ncand, nsel = len(cands), len(cands) + len(dleaves)
         sub = tab[sel].copy()
         S = sub[:, 5]
-        usize = sub[:, 7] * ((S + 15) // 16 * 16)
+        usize = S * ((sub[:, 7] + 15) // 16 * 16)          # ungapped rows, row-major, 16-byte pitch
         sub[:, 10] = _excl_cumsum(usize)
         sub[:, 9] = _excl_cumsum(S)
         sub[:, 8] = _excl_cumsum(sub[:, 7])

@@ -6,9 +6,11 @@
 // hand-rolled x86-64 context switch) of one OS thread.  A fiber runs until it reaches a synchronisation point:
 //   __syncthreads()                      - completes when every live thread of the workgroup has arrived
 //   __ballot / __any / __all / __shfl*   - complete when every live lane of the 64-wide wavefront is blocked; the lanes
-//                                          blocked at the SAME call site form the active set of the operation
+//                                          blocked at a wave operation form its active set (they must all be at the same
+//                                          operation with the same arguments — checked; the call SITE is not compared,
+//                                          an optimising compiler duplicates call sites into both arms of a branch)
 // A state in which nothing can complete (lanes of a wave split between different sync points for good) aborts with a
-// message: wave-level operations must be reached by all live lanes of a wave that are not parked at a barrier.
+// message: wave-level operations must be reached by all live lanes of a wave that are not parked at a barrier or done.
 // MPRG_EMU_ORDER=reverse runs the fibers of a workgroup in descending thread order (shakes out order dependence).
 #pragma once
 #include <stdint.h>
@@ -34,6 +36,8 @@ struct dim3 {
   unsigned x, y, z;
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
 typedef void *hipStream_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
@@ -111,11 +115,15 @@ inline void die(const char *what) {
   }
   abort();
 }
-inline void resolve_wave_group(int w0, int w1, const void *site) {
-  // the lanes of [w0, w1) blocked at `site` are the active set
+inline void resolve_wave_group(int w0, int w1, const void *) {
+  // the lanes of [w0, w1) blocked at a wave operation are its active set; they must agree on the operation
   uint64_t active = 0;
-  for (int l = w0; l < w1; ++l) if (fibers[l].state == AT_WAVE && fibers[l].site == site) active |= 1ull << (l - w0);
+  for (int l = w0; l < w1; ++l) if (fibers[l].state == AT_WAVE) active |= 1ull << (l - w0);
   int first = __builtin_ctzll(active);
+  for (int l = w0; l < w1; ++l)
+    if (((active >> (l - w0)) & 1) && (fibers[l].op != fibers[w0 + first].op || fibers[l].width != fibers[w0 + first].width ||
+                                       (fibers[l].op != OP_SHFL && fibers[l].arg != fibers[w0 + first].arg)))
+      die("divergent wave operation: the lanes of a wave are blocked at different ballots / shuffles");
   uint64_t ballot = 0;
   for (int l = w0; l < w1; ++l) if ((active >> (l - w0)) & 1) if (fibers[l].payload) ballot |= 1ull << (l - w0);
   for (int l = w0; l < w1; ++l) {
