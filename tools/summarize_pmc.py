@@ -1,11 +1,20 @@
-"""Turn rocprofv3 --pmc CSVs (separate FETCH_SIZE and WRITE_SIZE passes) into profiles/<round>/pmc_summary.json.
-HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 following /opt/skills/guides/MI355X_MICROARCH.md §HBM
-(FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read).
-usage: python tools/summarize_pmc.py <fetch.csv> <write.csv> <bench.json of the same run> <out.json>"""
+"""Turn rocprofv3 outputs of ONE commit into profiles/<round>/pmc_summary.json:
+  kernel stats CSV (--kernel-trace --stats)   -> average duration per kernel
+  --pmc FETCH_SIZE and --pmc WRITE_SIZE CSVs  -> HBM-side bytes per launch (separate passes, as the guide prescribes)
+  bench JSON of the run under the profiler     -> algorithmic bytes per launch (roofline.kernels, exclusive pass)
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read
+(/opt/skills/guides/MI355X_MICROARCH.md, HBM section: x2); narrower access patterns are uncalibrated there, so both the raw
+and the doubled figure are kept and the summary says which one the ratio uses (x2 — calibrated here on k_column_masks'
+4-byte-per-lane stream: 2 x FETCH_SIZE = 1.00-1.10 x its byte count, profiles/r02/masks_config_d/summary.json).
+usage: python tools/summarize_pmc.py <kernel_stats.csv> <fetch.csv> <write.csv> <bench.json of the same run> <out.json>"""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_digest  # noqa: E402
 
 
 def per_kernel(path):
@@ -17,26 +26,56 @@ def per_kernel(path):
     return agg
 
 
-fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
-bench = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
-alg = {k.replace("mprg_", "k_"): v for k, v in bench["config"]["kernels"].items()}
-names = {"k_kmeans_restart": "mprg_kmeans_restarts", "k_column_masks": "mprg_column_masks", "k_partition": "mprg_partition",
-         "k_ungap_dedupe": "mprg_ungap_dedupe", "k_emit_alleles": "mprg_emit_alleles"}
-out = {}
-for k in sorted(set(fetch) | set(write)):
-    if not k.startswith("k_"):
-        continue
-    calls = max(fetch[k][0], write[k][0], 1)
-    f_kb, w_kb = fetch[k][1] / max(fetch[k][0], 1), write[k][1] / max(write[k][0], 1)
-    rec = dict(launches=calls, fetch_size_kib_per_launch=round(f_kb, 1), write_size_kib_per_launch=round(w_kb, 1),
-               hbm_bytes_per_launch=round((2 * f_kb + w_kb) * 1024))
-    b = bench["config"]["kernels"].get(names.get(k, ""))
-    if b and b.get("GBps"):
-        alg_bytes = b["GBps"] * 1e6 * b["ms"] / b["calls"]
-        rec["algorithmic_bytes_per_launch"] = round(alg_bytes)
-        rec["traffic_over_algorithmic"] = round(rec["hbm_bytes_per_launch"] / alg_bytes, 3)
-    out[k] = rec
-json.dump(dict(source=dict(fetch=sys.argv[1], write=sys.argv[2], bench=sys.argv[3]),
-               config=dict(batch=bench["config"]["batch_per_gpu"], streams=bench["config"].get("host_threads_streams_per_gpu")),
-               kernels=out), open(sys.argv[4], "w"), indent=1)
-print(json.dumps(out, indent=1))
+def main():
+    stats_csv, fetch_csv, write_csv, bench_json, out_json = sys.argv[1:6]
+    stats = {r["Name"].split("(")[0]: r for r in csv.DictReader(open(stats_csv))}
+    fetch, write = per_kernel(fetch_csv), per_kernel(write_csv)
+    bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
+    alg = {}
+    for k in bench["roofline"]["kernels"]:
+        for kernel in k["kernel"].replace("(", " ").replace(")", " ").replace("+", " ").replace(",", " ").split():
+            if kernel.startswith("k_"):
+                alg.setdefault(kernel, k)
+    out = {}
+    for name in sorted(set(fetch) | set(write) | set(stats)):
+        if not name.startswith("k_"):
+            continue
+        rec = {}
+        if name in stats:
+            rec.update(launches=int(stats[name]["Calls"]), avg_us=round(float(stats[name]["AverageNs"]) / 1e3, 2),
+                       share_of_kernel_time_pct=round(float(stats[name]["Percentage"]), 2))
+        f_kb = fetch[name][1] / max(fetch[name][0], 1) if name in fetch else None
+        w_kb = write[name][1] / max(write[name][0], 1) if name in write else None
+        if f_kb is not None and w_kb is not None:
+            rec.update(fetch_size_kib_per_launch=round(f_kb, 1), write_size_kib_per_launch=round(w_kb, 1),
+                       hbm_bytes_per_launch_raw=round((f_kb + w_kb) * 1024), hbm_bytes_per_launch=round((2 * f_kb + w_kb) * 1024))
+        if name in out:
+            continue
+        out[name] = rec
+    # algorithmic bytes are attributed per ENTRY POINT (several kernels): sum the kernels of one entry point
+    groups = collections.defaultdict(list)
+    for k in bench["roofline"]["kernels"]:
+        names = [w for w in k["kernel"].replace("(", " ").replace(")", " ").replace("+", " ").replace(",", " ").split() if w.startswith("k_")]
+        groups[k["entry_point"]] = (names, k)
+    entry = {}
+    for ep, (names, k) in groups.items():
+        hbm = sum(out.get(n, {}).get("hbm_bytes_per_launch", 0) * out.get(n, {}).get("launches", 0) for n in names)
+        us = sum(out.get(n, {}).get("avg_us", 0) * out.get(n, {}).get("launches", 0) for n in names)
+        rec = dict(kernels=names, bench_launches=k["launches"], bench_ms=k["ms"], rocprof_ms=round(us / 1e3, 3),
+                   algorithmic_bytes=k["algorithmic_bytes_per_launch"] and round(k["algorithmic_bytes_per_launch"] * k["launches"]),
+                   hbm_bytes=round(hbm))
+        if rec["algorithmic_bytes"]:
+            rec["traffic_over_algorithmic"] = round(hbm / rec["algorithmic_bytes"], 3)
+            rec["achieved_GBps_rocprof"] = round(rec["algorithmic_bytes"] / max(us, 1e-9) * 1e-3, 2)
+            rec["frac_of_8TBps"] = round(rec["achieved_GBps_rocprof"] / 8000, 5)
+        entry[ep] = rec
+    json.dump(dict(source_digest=source_digest(), fetch_correction="2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes)",
+                   sources=dict(stats=stats_csv, fetch=fetch_csv, write=write_csv, bench=bench_json),
+                   bench_config=dict(batch=bench["config"]["batch_per_gpu"], workers=bench["config"]["host_worker_processes_per_gpu"],
+                                     streams=bench["config"]["streams_per_worker"]),
+                   kernels=out, entry_points=entry), open(out_json, "w"), indent=1)
+    print(json.dumps(entry, indent=1))
+
+
+if __name__ == "__main__":
+    main()
