@@ -245,7 +245,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
                      "--master-port P bench.py --gpus N ...")
-    ncpu = os.cpu_count() or 1
+    from make_prg_amd.utils.misc import effective_cpus
+    ncpu = effective_cpus()          # affinity and cgroup quota, not the machine's core count
     cpu = None
     # CPU baseline first, before this process or its workers touch the GPU (fork-safe, and nothing else is running)
     if world == 1 and not args.no_cpu_baseline:
@@ -267,12 +268,12 @@ def main():
     import multiprocessing as mp
     ctx = mp.get_context("fork")
     W = max(0, min(args.workers, args.batch))
-    if W > 1:          # stay inside the host: at most half the CPUs and a quarter of the free memory (~4 GiB per worker)
+    if W > 1:          # stay inside the host: the CPUs this process may use and a quarter of the free memory (~4 GiB per worker)
         try:
             avail_kib = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1])
         except Exception:
             avail_kib = 64 << 20
-        W = max(1, min(W, ncpu // (2 * max(world, 1)), int(avail_kib / (4 << 20) / 4 / max(world, 1))))
+        W = max(1, min(W, max(1, (ncpu - 1) // max(world, 1)), int(avail_kib / (4 << 20) / 4 / max(world, 1))))
     seeds = list(range(args.batch))           # the same alignments on every rank: each rank's work is verifiable
     gen_procs = args.gen_procs or max(1, min(16, ncpu // (max(W, 1) * max(world, 1))))
     conns, procs = [], []

@@ -36,7 +36,8 @@ def main(argv=None):
             # "all available": host worker processes per GPU stop paying at ~10 (16 are slower than 10 —
             # the processes' queues are time-sliced on the one device), and the ranks of a node share its cores
             local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-            args.threads = max(1, min(MAX_WORKERS_PER_GPU, (os.cpu_count() or 1) // local_world))
+            from .utils.misc import effective_cpus
+            args.threads = max(1, min(MAX_WORKERS_PER_GPU, effective_cpus() // local_world))
         args.func(args)
     else:
         parser.print_help()

@@ -1,18 +1,36 @@
-"""Host-side native helpers of libmprg (include/mprg.h, functions ending in _host): the one-pass .bin and .gfa encoders.
-The library is the product's own shared object (make_prg_amd/_lib/libmprg_hip.so); these entry points touch no GPU, so they
-are also usable before / without a device.  If the library cannot be loaded the callers keep their Python forms."""
+"""Host-side native helpers (include/mprg.h, functions ending in _host that touch no device): the one-pass .bin and .gfa
+encoders and the FASTA parser.  They are bound from libmprg_host.so — the same sources as in libmprg_hip.so, built with
+plain g++ WITHOUT the HIP runtime (csrc/mprg_host.cpp) — because this module is used by parent processes that are about to
+fork GPU workers and by processes that have not imported torch yet: loading the HIP library there would bring a HIP
+runtime into the process too early.  If the library is missing the callers keep their Python forms."""
 import ctypes
 import os
 from typing import Optional
 
 import numpy as np
 
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_LIB_PATH = os.environ.get("MPRG_HOST_LIB") or os.path.join(_PKG, "_lib", "libmprg_host.so")
+_LL, _P = ctypes.c_longlong, ctypes.c_void_p
+HOST_SIGNATURES = {
+    "mprg_prg_encode_host": (_LL, [_P, _LL, _P]),
+    "mprg_gfa_text_host": (_LL, [_P, _LL, _P, _LL]),
+    "mprg_fasta_scan_host": (_LL, [_P, _LL, _P, _P]),
+    "mprg_fasta_fill_host": (_LL, [_P, _LL, _P, _LL, _P]),
+}
 _lib = None
 _tried = False
 
 
+def bind_host(lib):
+    for name, (res, args) in HOST_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
 def set_library(lib):
-    """Tests inject the emulation build (same sources) here."""
+    """Tests inject a library here (the emulation build exports the same functions); None: Python forms only."""
     global _lib, _tried
     _lib, _tried = lib, True
 
@@ -21,10 +39,9 @@ def library():
     global _lib, _tried
     if not _tried:
         _tried = True
-        from ..backend import HIP_LIB_PATH, bind
-        if os.path.exists(HIP_LIB_PATH):
+        if os.path.exists(HOST_LIB_PATH):
             try:
-                _lib = bind(ctypes.CDLL(HIP_LIB_PATH))
+                _lib = bind_host(ctypes.CDLL(HOST_LIB_PATH))
             except (OSError, AttributeError):
                 _lib = None
     return _lib

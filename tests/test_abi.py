@@ -27,6 +27,21 @@ def test_hip_library_builds_and_exports_the_declared_abi():
     assert b"hip gfx950" in backend.bind(lib).mprg_version()
 
 
+def test_host_library_builds_without_the_hip_runtime():
+    """libmprg_host.so: the host-only entry points (encoders, FASTA parser), same sources, no HIP dependency — what
+    make_prg_amd.utils.native binds, so that parents of GPU worker processes never load a HIP runtime."""
+    import subprocess
+    from make_prg_amd.utils import native
+    path = ge.build_host()
+    lib = native.bind_host(ctypes.CDLL(path))
+    for name in native.HOST_SIGNATURES:
+        assert name in declared_symbols() and hasattr(lib, name)
+    needed = subprocess.run(["ldd", path], capture_output=True, text=True).stdout
+    assert "amdhip" not in needed and "hsa" not in needed
+    out = np.empty(8, np.uint32)
+    assert lib.mprg_prg_encode_host(b"AC 5 G 6 T 5 ", 13, out.ctypes.data) == 7 and out[:7].tolist() == [1, 2, 5, 3, 6, 4, 6]
+
+
 def test_host_rng_matches_numpy_randomstate():
     lib = backend.bind(ctypes.CDLL(ge.build_hip()))
     out = np.zeros(500)
