@@ -147,7 +147,12 @@ int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int
  * best restart, n distinct labels, total Elkan iterations, -, -, -}.
  * Workspace size per problem (doubles): mprg_kmeans_workspace_doubles(D, V, k_max, restart slots). */
 int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_restart_slots);
-int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, void *stream);
+/* mprg_kmeans_prepare, problem lists (both NULL: every problem takes the global-memory form): the problems of lds_list
+ * (int32 rows of `prob`) stage their matrix in LDS — lds_bytes >= 8 * (D * (V | 1) + 2 * V) for each of them, at most
+ * MPRG_KMEANS_PREPARE_LDS_MAX — so that the ordered reductions read LDS; other_list takes the rest. */
+enum { MPRG_KMEANS_PREPARE_LDS_MAX = 64 * 1024 };
+int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, const int32_t *lds_list,
+                        int n_lds, int64_t lds_bytes, const int32_t *other_list, int n_other, void *stream);
 int mprg_kmeans_restarts(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
                          double *ws, int32_t *km_status, void *stream);
 int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *xcounts,

@@ -126,9 +126,14 @@ int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_res
   return km_common_doubles_host(D, V) + (int64_t)n_restart_slots * km_restart_doubles_host(D, V);
 }
 
-int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, void *stream) {
+int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, const int32_t *lds_list,
+                        int n_lds, int64_t lds_bytes, const int32_t *other_list, int n_other, void *stream) {
   if (n_probs <= 0) return 0;
-  LAUNCH(k_kmeans_prepare, n_probs, 256, stream, prob, xcounts, ws);
+  if (!lds_list && !other_list) { n_lds = 0; n_other = n_probs; }
+  else if (n_lds + n_other != n_probs) return fail("mprg_kmeans_prepare: the two problem lists must cover the problems");
+  if (n_lds > 0 && (lds_bytes <= 0 || lds_bytes > MPRG_KMEANS_PREPARE_LDS_MAX)) return fail("mprg_kmeans_prepare: lds_bytes out of range");
+  if (n_other > 0) LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws);
+  if (n_lds > 0) LAUNCH_LDS(k_kmeans_prepare_lds, n_lds, 256, lds_bytes, stream, lds_list, prob, xcounts, ws);
   return check_launch("k_kmeans_prepare");
 }
 

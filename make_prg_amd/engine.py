@@ -22,6 +22,7 @@ MAX_CLUSTERS = 10   # from_msa/cluster_sequences.py:23
 N_INIT = 10         # scikit-learn 1.3.0 default the reference's pinned environment runs with
 ROWS_PER_CHUNK = 512
 import os as _os
+PREPARE_LDS_MAX = 64 * 1024          # MPRG_KMEANS_PREPARE_LDS_MAX
 FUSED_CLUSTER_FURTHER = _os.environ.get("MPRG_FUSED_CLUSTER_FURTHER", "1") != "0"     # one-workgroup form for small problems
 TILE_COLS = 1024
 IUPAC = {"R": "GA", "Y": "TC", "K": "GT", "M": "AC", "S": "GC", "W": "AT", "A": "A", "C": "C", "G": "G", "T": "T"}
@@ -396,6 +397,17 @@ class BatchEngine:
         self.counters["launches"] += 2
         return be.download(d_further, np.int32, nA).astype(bool)
 
+    def _kmeans_prepare(self, d_ptab, D, V, d_x, d_ws):
+        """mprg_kmeans_prepare with the problems split by whether their matrix fits the LDS budget (include/mprg.h)."""
+        be = self.be
+        need = 8 * (D * (V | 1) + 2 * V)
+        in_lds = need <= PREPARE_LDS_MAX
+        i_l, i_o = np.nonzero(in_lds)[0].astype(np.int32), np.nonzero(~in_lds)[0].astype(np.int32)
+        d_il, d_io = be.upload(i_l), be.upload(i_o)
+        be.call("mprg_kmeans_prepare", be.ptr(d_ptab), len(D), be.ptr(d_x), be.ptr(d_ws), be.ptr(d_il), len(i_l),
+                int(need[in_lds].max()) if len(i_l) else 0, be.ptr(d_io), len(i_o), be.stream,
+                work=float((8 * D * V).sum()))
+
     def _dedupe(self, d_sub, d_rowidx, n_views: int, tot_rows: int, tot_u: int, work: float = 0.0, sub=None):
         """mprg_ungap_dedupe over the views of `d_sub`; returns the device buffers by name."""
         be = self.be
@@ -525,7 +537,7 @@ class BatchEngine:
         d_labels, d_kmst, d_info = be.empty(4 * lo), be.zeros(4 * P), be.empty(64 * P)
         be.call("mprg_kmer_counts", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(d_ucodes), be.ptr(d_ulen),
                 be.ptr(d_seqrow), be.ptr(d_occ), be.ptr(d_table), be.ptr(d_x), be.stream)
-        be.call("mprg_kmeans_prepare", be.ptr(d_ptab), P, be.ptr(d_x), be.ptr(d_ws), be.stream)
+        self._kmeans_prepare(d_ptab, ptab[:, 1], ptab[:, 7], d_x, d_ws)
         self.counters["launches"] += 3
 
         for p in probs:

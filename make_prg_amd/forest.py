@@ -330,7 +330,7 @@ class ForestEngine(BatchEngine):
         d_labels, d_assign = be.empty(4 * lo * NS), be.zeros(4 * lo)
         be.call("mprg_kmer_counts", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
                 be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_x), be.stream)
-        be.call("mprg_kmeans_prepare", be.ptr(d_ptab), P, be.ptr(d_x), be.ptr(d_ws), be.stream)
+        self._kmeans_prepare(d_ptab, D, V, d_x, d_ws)
         self.counters["launches"] += 3
         d_uni, uoff = self._uniforms_all()
         uoff_arr = np.zeros(MAX_CLUSTERS + 1, np.int64)

@@ -33,7 +33,12 @@ def run_kmeans_fits(be, fits, n_init=10, path="global", lds_limit=None):
         ki = np.zeros((P, 5), np.int32)
         ki[:, 0], ki[:, 1] = np.arange(P), k
         d_ki = be.upload(ki)
-        be.call("mprg_kmeans_prepare", be.ptr(d_p), P, be.ptr(d_x), be.ptr(d_ws), be.stream)
+        need = 8 * (ptab[:, 1] * (ptab[:, 7] | 1) + 2 * ptab[:, 7])
+        in_lds = (need <= 64 * 1024) & (np.arange(P) % 5 != 4)          # every fifth problem: the global-memory form
+        i_l, i_o = np.nonzero(in_lds)[0].astype(np.int32), np.nonzero(~in_lds)[0].astype(np.int32)
+        d_il, d_io = be.upload(i_l), be.upload(i_o)
+        be.call("mprg_kmeans_prepare", be.ptr(d_p), P, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_il), len(i_l),
+                int(need[in_lds].max()) if len(i_l) else 0, be.ptr(d_io), len(i_o), be.stream)
         use_lds = np.zeros(P, bool)
         if path == "lds":
             Dv, Vv = np.ascontiguousarray(ptab[:, 1]), np.ascontiguousarray(ptab[:, 7])
