@@ -95,7 +95,8 @@ def source_digest():
     """sha256 over the kernel sources + the host that drives them: ties a committed PMC summary to the code it measured."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "make_prg_amd", "csrc")
-    for name in sorted(os.listdir(d)) + ["../forest.py", "../engine.py"]:
+    names = [n for n in sorted(os.listdir(d)) if n.endswith((".inc", ".hip", ".h", ".cpp"))]
+    for name in names + ["../forest.py", "../engine.py"]:
         with open(os.path.join(d, name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -195,19 +195,14 @@ int mprg_commit_labels(const int64_t *prob, int n_probs, const int32_t *labels, 
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
                          int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                          const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
-                         int32_t *scratch, int32_t *out_further, const int32_t *fused_list, int n_fused, void *stream) {
+                         int32_t *scratch, int32_t *out_further, void *stream) {
   if (n_probs <= 0) return 0;
   if (k < 1 || k > KM_KMAX) return fail("mprg_cluster_further: k out of range");
   if (hipMemsetAsync(out_further, 0, sizeof(int32_t) * n_probs, (hipStream_t)stream) != hipSuccess) return fail("memset");
-  if (n_work_cols > 0)
-    LAUNCH(k_cluster_majority, n_work_cols, CF_TILE, stream, arena, views, rowidx, prob, work_cols, k, d_of_row, labels,
-           assign, scratch);
-  if (n_work_rows > 0)
-    LAUNCH(k_cluster_hamming, n_work_rows, CF_TILE, stream, arena, views, rowidx, prob, work_rows, d_of_row, labels,
-           (const int32_t *)scratch, out_further);
-  if (n_fused > 0)
-    LAUNCH(k_cluster_further_fused, n_fused, CF_TILE, stream, fused_list, arena, views, rowidx, prob, k, d_of_row, labels,
-           assign, out_further);
+  LAUNCH(k_cluster_majority, n_work_cols, CF_TILE, stream, arena, views, rowidx, prob, work_cols, k, d_of_row, labels,
+         assign, scratch);
+  LAUNCH(k_cluster_hamming, n_work_rows, CF_TILE, stream, arena, views, rowidx, prob, work_rows, d_of_row, labels,
+         (const int32_t *)scratch, out_further);
   return check_launch("k_cluster_further");
 }
 
@@ -229,7 +224,7 @@ int mprg_leaf_jobs(const int64_t *leaves, int64_t n_leaves, const int32_t *rowid
 
 int mprg_emit_alleles(const uint8_t *arena, const int64_t *jobs, int64_t n_jobs, uint8_t *out, void *stream) {
   if (n_jobs <= 0) return 0;
-  LAUNCH(k_emit_alleles, (n_jobs + 255) / 256, 256, stream, arena, jobs, (long long)n_jobs, out);
+  LAUNCH(k_emit_alleles, (n_jobs + 3) / 4, EMIT_THREADS, stream, arena, jobs, (long long)n_jobs, out);      // a wavefront per job
   return check_launch("k_emit_alleles");
 }
 

@@ -21,9 +21,7 @@ BIT_GAP, BIT_N, BITS_IUPAC = 1 << 4, 1 << 11, 0x7E0
 MAX_CLUSTERS = 10   # from_msa/cluster_sequences.py:23
 N_INIT = 10         # scikit-learn 1.3.0 default the reference's pinned environment runs with
 ROWS_PER_CHUNK = 512
-import os as _os
-PREPARE_LDS_MAX = 64 * 1024          # MPRG_KMEANS_PREPARE_LDS_MAX
-FUSED_CLUSTER_FURTHER = _os.environ.get("MPRG_FUSED_CLUSTER_FURTHER", "1") != "0"     # one-workgroup form for small problems
+PREPARE_LDS_MAX = 64 * 1024          # MPRG_KMEANS_PREPARE_LDS_MAX (include/mprg.h)
 TILE_COLS = 1024
 IUPAC = {"R": "GA", "Y": "TC", "K": "GT", "M": "AC", "S": "GC", "W": "AT", "A": "A", "C": "C", "G": "G", "T": "T"}
 
@@ -370,30 +368,26 @@ class BatchEngine:
 
     def _cluster_further(self, d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further):
         """mprg_cluster_further for the problems of act_tab (rows of the problem table); returns bool per problem.
-        Small problems (the rule) take the fused one-workgroup form with the view's cells in LDS (include/mprg.h)."""
+        (A one-workgroup form with the view's cells in LDS was built and measured in round 2: 10.3 ms against 7.4 ms per
+        3 000 alignments — its 58 KB of LDS halve the residency of a kernel that is bound by instruction issue — dropped.)"""
         be = self.be
         nA = len(act_tab)
         views = act_tab[:, 0]
-        Sv, nv = sub[views, 5], sub[views, 7]
-        pitch = (nv + 3) // 4 * 4
-        pitch = pitch + np.where((pitch // 4) % 2 == 0, 4, 0)
-        fused = FUSED_CLUSTER_FURTHER & (Sv <= 512) & (nv <= 1024) & (Sv * pitch <= 16384) & (Sv > 0) & (nv > 0)
-        i_f, i_o = np.nonzero(fused)[0].astype(np.int32), np.nonzero(~fused)[0]
-        ncol_t = (nv[i_o] + 255) // 256
-        nrow_t = (Sv[i_o] + 255) // 256
+        ncol_t = (sub[views, 7] + 255) // 256
+        nrow_t = (sub[views, 5] + 255) // 256
 
         def items(cnt):
             w = np.empty((int(cnt.sum()), 2), np.int32)
-            w[:, 0] = np.repeat(i_o, cnt)
+            w[:, 0] = np.repeat(np.arange(nA), cnt)
             w[:, 1] = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
             return w
 
         wc, wr = items(ncol_t), items(nrow_t)
-        d_sp, d_wc, d_wr, d_if = be.upload(act_tab), be.upload(wc), be.upload(wr), be.upload(i_f)
+        d_sp, d_wc, d_wr = be.upload(act_tab), be.upload(wc), be.upload(wr)
         be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp), nA, k,
                 be.ptr(d_dor), be.ptr(d_labels) if k > 1 else None, be.ptr(d_assign) if (k > 1 and d_assign is not None) else None,
-                be.ptr(d_wc), len(wc), be.ptr(d_wr), len(wr), be.ptr(d_scratch), be.ptr(d_further), be.ptr(d_if), len(i_f),
-                be.stream, work=float((Sv * nv).sum()))      # the members' cells, read once per evaluated k
+                be.ptr(d_wc), len(wc), be.ptr(d_wr), len(wr), be.ptr(d_scratch), be.ptr(d_further), be.stream,
+                work=float((sub[views, 5] * sub[views, 7]).sum()))      # the members' cells, read once per evaluated k
         self.counters["launches"] += 2
         return be.download(d_further, np.int32, nA).astype(bool)
 
