@@ -157,20 +157,16 @@ int mprg_kmeans_restarts(const int64_t *prob, const int32_t *kinfo, int n_fits, 
                          double *ws, int32_t *km_status, void *stream);
 int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *xcounts,
                        double *ws, int32_t *labels, double *km_info, void *stream);
-/* A11, LDS-resident form of restarts + select for fits whose working set fits a CU's LDS (the rule for pan-genome
- * alignments): one workgroup per fit keeps the centred matrix, the k-means++ tables and G restarts' centres, bounds and
- * labels in LDS, runs the n_init restarts in ceil(n_init / G) passes, keeps the best restart by the reference's rule and
- * writes predict()'s labels, km_info and km_status exactly as mprg_kmeans_restarts + mprg_kmeans_select would
- * (mprg_kmeans_prepare must have run; no per-restart workspace is touched).  kinfo as above except field 2 = G.
- * mprg_kmeans_lds_plan (host arrays) gives, per fit (D, V, k), the G to use under `limit_bytes` of LDS (0: does not fit
- * even with one restart — use the global-memory entry points) and the dynamic LDS bytes it needs; `lds_bytes` of a launch
- * must be >= the need of every fit in it (bin fits by need so that small ones share a CU: 160 KiB per CU). */
-enum { MPRG_KMEANS_LDS_MAX = 160 * 1024 - 64 };
-int mprg_kmeans_lds_plan(const int64_t *D_host, const int64_t *V_host, const int32_t *k_host, int n, int n_init,
-                         int64_t limit_bytes, int32_t *out_G_host, int64_t *out_bytes_host);
-int mprg_kmeans_fit_lds(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
-                        const double *xcounts, const double *ws, int32_t *labels, double *km_info, int32_t *km_status,
-                        int64_t lds_bytes, void *stream);
+/* A11, restarts + select as ONE launch of persistent workgroups (the throughput form): at most n_slots workgroups, each
+ * taking fits b, b + n_slots, ... and keeping the per-restart arrays of its current fit in its own scratch slot
+ * (slot_ws + b * slot_stride_doubles; slot_stride_doubles >= n_init * mprg_kmeans_workspace_doubles' per-restart part for
+ * every fit of the launch, i.e. (mprg_kmeans_workspace_doubles(D, V, k_max, n_init) - mprg_kmeans_workspace_doubles(D, V,
+ * k_max, 0))).  The problems' workspaces (`ws`, prob[WS_OFF]) then only need their common part
+ * (mprg_kmeans_workspace_doubles(D, V, k_max, 0)), written by mprg_kmeans_prepare and read-only here.  Outputs as
+ * mprg_kmeans_restarts + mprg_kmeans_select; kinfo field 2 is ignored. */
+int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
+                    const double *xcounts, double *ws, double *slot_ws, int64_t slot_stride_doubles, int n_slots,
+                    int32_t *labels, double *km_info, int32_t *km_status, void *stream);
 /* labels of accepted fits -> the problems' assignment (read by mprg_split_children) */
 int mprg_commit_labels(const int64_t *prob, int n_probs, const int32_t *labels, int32_t *assign, void *stream);
 /* fills out[n] with numpy.random.RandomState(seed).random_sample(n) (host memory; MT19937) */

@@ -11,7 +11,6 @@
 #include "k_rows.inc"
 #include "k_kmer.inc"
 #include "k_kmeans.inc"
-#include "k_kmeans_lds.inc"
 #include "k_cluster.inc"
 #include "k_emit.inc"
 #include "host_encoders.inc"
@@ -146,44 +145,23 @@ int mprg_kmeans_restarts(const int64_t *prob, const int32_t *kinfo, int n_fits, 
   return check_launch("k_kmeans_restart");
 }
 
+int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
+                    const double *xcounts, double *ws, double *slot_ws, int64_t slot_stride_doubles, int n_slots,
+                    int32_t *labels, double *km_info, int32_t *km_status, void *stream) {
+  if (n_fits <= 0) return 0;
+  if (n_init > KM_RMAX) return fail("n_init must be <= 16");
+  if (n_slots <= 0 || slot_stride_doubles <= 0) return fail("mprg_kmeans_fit: no scratch slots");
+  const int grid = n_fits < n_slots ? n_fits : n_slots;
+  LAUNCH(k_kmeans_fit, grid, env_threads("MPRG_KM_THREADS", 256), stream, prob, kinfo, n_fits, n_init, uniforms_dev, xcounts, ws,
+         slot_ws, (long long)slot_stride_doubles, labels, km_info, km_status);
+  return check_launch("k_kmeans_fit");
+}
+
 int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *xcounts,
                        double *ws, int32_t *labels, double *km_info, void *stream) {
   if (n_fits <= 0) return 0;
   LAUNCH(k_kmeans_select, n_fits, 256, stream, prob, kinfo, n_init, xcounts, ws, labels, km_info);
   return check_launch("k_kmeans_select");
-}
-
-int mprg_kmeans_lds_plan(const int64_t *D_host, const int64_t *V_host, const int32_t *k_host, int n, int n_init,
-                         int64_t limit_bytes, int32_t *out_G_host, int64_t *out_bytes_host) {
-  if (limit_bytes > MPRG_KMEANS_LDS_MAX) limit_bytes = MPRG_KMEANS_LDS_MAX;
-  for (int i = 0; i < n; ++i) {
-    const int D = (int)D_host[i], V = (int)V_host[i], k = k_host[i];
-    int G = 0;
-    if (k >= 1 && k <= KM_KMAX && D >= 1 && V >= 1 && D_host[i] * V_host[i] < (1LL << 24)) {
-      for (int g = n_init; g >= 1; --g) if (kl_lds_bytes(D, V, k, g) <= limit_bytes) { G = g; break; }
-      if (G > 0 && G < n_init) { const int passes = (n_init + G - 1) / G; G = (n_init + passes - 1) / passes; }
-    }
-    out_G_host[i] = G;
-    out_bytes_host[i] = G ? kl_lds_bytes(D, V, k, G) : 0;
-  }
-  return 0;
-}
-
-int mprg_kmeans_fit_lds(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
-                        const double *xcounts, const double *ws, int32_t *labels, double *km_info, int32_t *km_status,
-                        int64_t lds_bytes, void *stream) {
-  if (n_fits <= 0) return 0;
-  if (n_init > KM_RMAX) return fail("n_init must be <= 16");
-  if (lds_bytes <= 0 || lds_bytes > MPRG_KMEANS_LDS_MAX) return fail("mprg_kmeans_fit_lds: lds_bytes out of range (mprg_kmeans_lds_plan)");
-  static thread_local bool raised = false;
-  if (!raised) {          // a workgroup may take (nearly) all of a CU's 160 KiB; beyond 64 KiB HIP wants to be told
-    if (hipFuncSetAttribute((const void *)k_kmeans_fit_lds, hipFuncAttributeMaxDynamicSharedMemorySize, MPRG_KMEANS_LDS_MAX) != hipSuccess)
-      return fail("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    raised = true;
-  }
-  LAUNCH_LDS(k_kmeans_fit_lds, n_fits, KL_THREADS, lds_bytes, stream, prob, kinfo, n_init, uniforms_dev, xcounts, ws, labels,
-             km_info, km_status);
-  return check_launch("k_kmeans_fit_lds");
 }
 
 int mprg_commit_labels(const int64_t *prob, int n_probs, const int32_t *labels, int32_t *assign, void *stream) {

@@ -23,12 +23,11 @@ from .msa import CODE_GAP, decode
 
 KIND_LEAF, KIND_INTERVAL, KIND_CLUSTER = 0, 1, 2
 FUSED_VIEWS = os.environ.get("MPRG_FUSED_VIEWS", "1") != "0"     # fused small-view launch shape of mprg_partition
-# LDS-resident KMeans fits (mprg_kmeans_fit_lds).  Measured on MI355X (profiles/r02/kmeans_lds.md): 2.2x shorter per fit
-# than the global-memory kernels, but ~100 KB of LDS per fit leaves 1-2 fits per CU instead of 4, so the batch rate is
-# 0.8x: off by default until the per-fit footprint is halved (centres updated in place)
-KMEANS_LDS = os.environ.get("MPRG_KMEANS_LDS", "0") != "0"
-# dynamic-LDS size classes of mprg_kmeans_fit_lds launches: 4, 3, 2 and 1 workgroups per CU (160 KiB of LDS per CU)
-LDS_CLASSES = np.asarray([40 * 1024 - 64, 53 * 1024 - 64, 80 * 1024 - 64, 160 * 1024 - 64], np.int64)
+# KMeans fits as one launch of persistent workgroups with per-workgroup scratch slots (mprg_kmeans_fit); fits whose
+# per-restart arrays exceed SLOT_MAX_DOUBLES take mprg_kmeans_restarts + mprg_kmeans_select (one region per problem)
+KMEANS_SLOTS = os.environ.get("MPRG_KMEANS_SLOTS", "1") != "0"
+SLOT_MAX_DOUBLES = 1 << 16                                       # 512 KiB of scratch per resident workgroup
+SLOT_WGS_PER_CU = 4                                              # k_kmeans_fit: 256 threads, 4 waves per SIMD
 _ACGT = np.frombuffer(b"ACGT-RYKMSWN????", dtype=np.uint8)
 
 
@@ -317,12 +316,12 @@ class ForestEngine(BatchEngine):
                 be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), be.stream)
         V = be.download(d_V, np.int32, P).astype(np.int64)
         NS = self.k_slots                                      # k values fitted per round (speculation depth)
-        # LDS-resident fits (the rule) need the problem's common workspace only; the per-restart slots are for fits that
-        # do not fit a CU's LDS at some k (their largest k decides: the need grows with k) and for the speculative rounds
-        kmax_p = np.minimum(MAX_CLUSTERS, np.maximum(D - 1, 2)).astype(np.int32)
-        G_kmax, _ = self._lds_plan(D, V, kmax_p)
-        self._lds_ok = (G_kmax > 0) & (NS == 1) & KMEANS_LDS
-        wsz = D * V + 2 * V + D + 8 + 3 * D * D + np.where(self._lds_ok, 0, NS * N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512))   # mprg_kmeans_workspace_doubles
+        # per-restart arrays: scratch slots of the persistent workgroups for the fits that fit one (the rule) — their
+        # problems then need the common workspace only — else one region per problem behind the common part
+        rdoubles = N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)                  # mprg_kmeans_workspace_doubles, restart part
+        self._slot_ok = (rdoubles <= SLOT_MAX_DOUBLES) & (NS == 1) & KMEANS_SLOTS
+        self._rdoubles = rdoubles
+        wsz = D * V + 2 * V + D + 8 + 3 * D * D + np.where(self._slot_ok, 0, NS * rdoubles)
         ptab[:, 7], ptab[:, 8], ptab[:, 9], ptab[:, 10] = V, _excl_cumsum(D * V), _excl_cumsum(wsz), so
         lo = int(D.sum())
         d_ptab = be.upload(ptab)
@@ -476,58 +475,42 @@ class ForestEngine(BatchEngine):
         R["n_child"][pj] = nchild
 
     # ------------------------------------------------------------------------------------------------ KMeans rounds
-    def _lds_plan(self, D, V, k, limit=None):
-        """(G, dynamic LDS bytes) per fit for mprg_kmeans_fit_lds; G == 0: the fit does not fit a CU's LDS."""
-        n = len(D)
-        Dv, Vv, kv = (np.ascontiguousarray(D, np.int64), np.ascontiguousarray(V, np.int64), np.ascontiguousarray(k, np.int32))
-        G, nbytes = np.zeros(n, np.int32), np.zeros(n, np.int64)
-        if n:
-            self.be.lib.mprg_kmeans_lds_plan(Dv.ctypes.data, Vv.ctypes.data, kv.ctypes.data, n, N_INIT,
-                                             int(limit or (1 << 40)), G.ctypes.data, nbytes.ctypes.data)
-        return G, nbytes
-
     def _kmeans_round(self, active, k, D, V, uoff, d_ptab, d_uni, d_x, d_ws, d_labels):
-        """One k of the reference's loop (cluster_sequences.py:262-266) for the problems `active`: every fit whose working
-        set fits a CU's LDS goes to mprg_kmeans_fit_lds — one launch per LDS size class, so that small fits share a CU —
-        the others to the global-memory kernels.  Returns (active reordered by launch, status, km_info rows)."""
+        """One k of the reference's loop (cluster_sequences.py:262-266) for the problems `active`: one mprg_kmeans_fit launch
+        (persistent workgroups, scratch slots, selection fused) for the fits whose per-restart arrays fit a slot, the
+        two-launch form for the others.  Returns (active reordered by launch, status, km_info rows)."""
         be = self.be
-        G, nbytes = self._lds_plan(D[active], V[active], np.full(len(active), k, np.int32))
-        G = np.where(self._lds_ok[active], G, 0)
-        cls = np.searchsorted(LDS_CLASSES, nbytes, side="left")           # 0..len-1; G == 0 -> its own class at the end
-        cls = np.where(G > 0, cls, len(LDS_CLASSES))
-        order = np.lexsort((-(D[active] * V[active]), cls))              # class, then biggest fits first
-        active, G, nbytes, cls = active[order], G[order], nbytes[order], cls[order]
-        nA = len(active)
+        slot = self._slot_ok[active]
+        order = np.lexsort((-(D[active] * V[active]), ~slot))            # slot fits first, biggest first inside each form
+        active, slot = active[order], slot[order]
+        nA, n_slot = len(active), int(slot.sum())
         ki = np.empty((nA, 5), np.int32)
-        ki[:, 0], ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = active, k, G, uoff, 0
+        ki[:, 0], ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = active, k, 0, uoff, 0
         d_ki, d_st, d_info = be.upload(ki), be.zeros(4 * nA), be.empty(64 * nA)
-        timed = []                                                      # (entry point, its event slot, class) when profiling
-        for c in np.unique(cls):
-            m = np.nonzero(cls == c)[0]
-            lo, n = int(m[0]), len(m)
-            off = lambda buf, b: _Offset(be, buf, b * lo)
-            if c < len(LDS_CLASSES):
-                name = "mprg_kmeans_fit_lds"
-                be.call(name, be.ptr(d_ptab), be.ptr(off(d_ki, 20)), n, N_INIT, be.ptr(d_uni), be.ptr(d_x),
-                        be.ptr(d_ws), be.ptr(d_labels), be.ptr(off(d_info, 64)), be.ptr(off(d_st, 4)), int(nbytes[m].max()),
-                        be.stream)
-                self.counters["launches"] += 1
-                self.counters["fits_lds"] = self.counters.get("fits_lds", 0) + n
-            else:
-                name = "mprg_kmeans_restarts"
-                be.call(name, be.ptr(d_ptab), be.ptr(off(d_ki, 20)), n, N_INIT, be.ptr(d_uni), be.ptr(d_ws),
-                        be.ptr(off(d_st, 4)), be.stream)
-                be.call("mprg_kmeans_select", be.ptr(d_ptab), be.ptr(off(d_ki, 20)), n, N_INIT, be.ptr(d_x), be.ptr(d_ws),
-                        be.ptr(d_labels), be.ptr(off(d_info, 64)), be.stream)
-                self.counters["launches"] += 2
-            if be.profile is not None and be.profile.get(name):
-                timed.append((name, len(be.profile[name]) - 1, c))
+        timed = []                                                      # (entry point, its event slot, rows) when profiling
+        if n_slot:
+            stride = int(self._rdoubles[active[:n_slot]].max())
+            n_slots = min(n_slot, SLOT_WGS_PER_CU * be.n_cus)
+            d_slots = be.empty(8 * stride * n_slots)
+            be.call("mprg_kmeans_fit", be.ptr(d_ptab), be.ptr(d_ki), n_slot, N_INIT, be.ptr(d_uni), be.ptr(d_x), be.ptr(d_ws),
+                    be.ptr(d_slots), stride, n_slots, be.ptr(d_labels), be.ptr(d_info), be.ptr(d_st), be.stream)
+            self.counters["launches"] += 1
+            if be.profile is not None and be.profile.get("mprg_kmeans_fit"):
+                timed.append(("mprg_kmeans_fit", len(be.profile["mprg_kmeans_fit"]) - 1, slice(0, n_slot)))
+        if n_slot < nA:
+            n, off = nA - n_slot, lambda buf, b: _Offset(be, buf, b * n_slot)
+            be.call("mprg_kmeans_restarts", be.ptr(d_ptab), be.ptr(off(d_ki, 20)), n, N_INIT, be.ptr(d_uni), be.ptr(d_ws),
+                    be.ptr(off(d_st, 4)), be.stream)
+            be.call("mprg_kmeans_select", be.ptr(d_ptab), be.ptr(off(d_ki, 20)), n, N_INIT, be.ptr(d_x), be.ptr(d_ws),
+                    be.ptr(d_labels), be.ptr(off(d_info, 64)), be.stream)
+            self.counters["launches"] += 2
+            if be.profile is not None and be.profile.get("mprg_kmeans_restarts"):
+                timed.append(("mprg_kmeans_restarts", len(be.profile["mprg_kmeans_restarts"]) - 1, slice(n_slot, nA)))
         st = be.download(d_st, np.int32, nA)
         info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
-        for name, slot, c in timed:          # algorithmic bytes are known only after the fits: 8 D V (Elkan iterations + n_init)
-            m = cls == c
-            a0, a1, _ = be.profile[name][slot]
-            be.profile[name][slot] = (a0, a1, float((8.0 * D[active[m]] * V[active[m]] * (info[m, 4] + N_INIT)).sum()))
+        for name, ev, rows in timed:         # algorithmic bytes are known only after the fits: 8 D V (Elkan iterations + n_init)
+            a0, a1, _ = be.profile[name][ev]
+            be.profile[name][ev] = (a0, a1, float((8.0 * D[active[rows]] * V[active[rows]] * (info[rows, 4] + N_INIT)).sum()))
         return active, st, info
 
     # ------------------------------------------------------------------------------------------------ tables

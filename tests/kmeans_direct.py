@@ -4,10 +4,9 @@ import numpy as np
 PF = 12
 
 
-def run_kmeans_fits(be, fits, n_init=10, path="global", lds_limit=None):
-    """path: "global" = mprg_kmeans_restarts + mprg_kmeans_select (all per-restart state in the workspace);
-    "lds" = mprg_kmeans_fit_lds (one workgroup per fit, state in LDS; lds_limit bounds the plan so that fits run their
-    restarts in several passes)."""
+def run_kmeans_fits(be, fits, n_init=10, path="global", n_slots=3):
+    """path: "global" = mprg_kmeans_restarts + mprg_kmeans_select (one restart region per problem, two launches);
+    "fit" = mprg_kmeans_fit (persistent workgroups, per-restart arrays in `n_slots` scratch slots, selection fused)."""
     groups = {}
     for idx, f in enumerate(fits):
         groups.setdefault(f["k"], []).append(idx)
@@ -39,31 +38,19 @@ def run_kmeans_fits(be, fits, n_init=10, path="global", lds_limit=None):
         d_il, d_io = be.upload(i_l), be.upload(i_o)
         be.call("mprg_kmeans_prepare", be.ptr(d_p), P, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_il), len(i_l),
                 int(need[in_lds].max()) if len(i_l) else 0, be.ptr(d_io), len(i_o), be.stream)
-        use_lds = np.zeros(P, bool)
-        if path == "lds":
-            Dv, Vv = np.ascontiguousarray(ptab[:, 1]), np.ascontiguousarray(ptab[:, 7])
-            kv, G, nbytes = np.full(P, k, np.int32), np.zeros(P, np.int32), np.zeros(P, np.int64)
-            be.lib.mprg_kmeans_lds_plan(Dv.ctypes.data, Vv.ctypes.data, kv.ctypes.data, P, n_init,
-                                        lds_limit or (1 << 40), G.ctypes.data, nbytes.ctypes.data)
-            use_lds = G > 0                      # the others do not fit: global-memory kernels, as the host does
-            ki[:, 2] = G
-        info, st = np.zeros((P, 8)), np.zeros(P, np.int32)
-        for sel, lds in ((np.nonzero(use_lds)[0], True), (np.nonzero(~use_lds)[0], False)):
-            if not len(sel):
-                continue
-            d_ki = be.upload(ki[sel])
-            d_st1, d_info1 = be.zeros(4 * len(sel)), be.empty(64 * len(sel))
-            if lds:
-                be.call("mprg_kmeans_fit_lds", be.ptr(d_p), be.ptr(d_ki), len(sel), n_init, be.ptr(d_u), be.ptr(d_x),
-                        be.ptr(d_ws), be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), int(nbytes[sel].max()), be.stream)
-            else:
-                be.call("mprg_kmeans_restarts", be.ptr(d_p), be.ptr(d_ki), len(sel), n_init, be.ptr(d_u), be.ptr(d_ws),
-                        be.ptr(d_st1), be.stream)
-                be.call("mprg_kmeans_select", be.ptr(d_p), be.ptr(d_ki), len(sel), n_init, be.ptr(d_x), be.ptr(d_ws),
-                        be.ptr(d_lab), be.ptr(d_info1), be.stream)
-            info[sel] = be.download(d_info1, np.float64, 8 * len(sel)).reshape(len(sel), 8)
-            st[sel] = be.download(d_st1, np.int32, len(sel))
-        run_kmeans_fits.lds_fits += int(use_lds.sum())
+        d_st1, d_info1 = be.zeros(4 * P), be.empty(64 * P)
+        if path == "fit":
+            W = lambda D, V, r: int(be.lib.mprg_kmeans_workspace_doubles(int(D), int(V), 10, r))
+            stride = max(W(ptab[i, 1], ptab[i, 7], n_init) - W(ptab[i, 1], ptab[i, 7], 0) for i in range(P))
+            d_slots = be.empty(8 * stride * n_slots)
+            be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws),
+                    be.ptr(d_slots), stride, n_slots, be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
+        else:
+            be.call("mprg_kmeans_restarts", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_u), be.ptr(d_ws), be.ptr(d_st1), be.stream)
+            be.call("mprg_kmeans_select", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_lab),
+                    be.ptr(d_info1), be.stream)
+        info = be.download(d_info1, np.float64, 8 * P).reshape(P, 8)
+        st = be.download(d_st1, np.int32, P)
         labels = be.download(d_lab, np.int32, lo)
         for i, idx in enumerate(idxs):
             D = fits[idx]["shape"][0]
@@ -71,6 +58,3 @@ def run_kmeans_fits(be, fits, n_init=10, path="global", lds_limit=None):
             results[idx] = dict(labels=labels[o:o + D].tolist(), inertia_hex=float(info[i, 0]).hex(),
                                 n_iter=int(info[i, 1]), status=int(st[i]))
     return results
-
-
-run_kmeans_fits.lds_fits = 0          # how many fits the LDS entry point took so far (tests assert it was exercised)

@@ -42,15 +42,13 @@ def test_kmeans_known_answers(hip, golden_kmeans):
         assert g["n_iter"] == f["n_iter"]
 
 
-def test_kmeans_known_answers_lds_resident_fits(hip, golden_kmeans):
-    """The same scikit-learn answers through mprg_kmeans_fit_lds (one workgroup per fit, working set in LDS), once with
-    every restart resident and once with an LDS budget that forces several passes of restarts."""
+def test_kmeans_known_answers_persistent_workgroups(hip, golden_kmeans):
+    """The same scikit-learn answers through mprg_kmeans_fit (persistent workgroups, per-restart arrays in scratch slots,
+    selection fused), with a few slots (many fits per workgroup) and with as many slots as fits."""
     from tests.kmeans_direct import run_kmeans_fits
     fits = golden_kmeans["fits"]
-    for limit in (None, 70000):
-        before = run_kmeans_fits.lds_fits
-        got = run_kmeans_fits(hip, fits, path="lds", lds_limit=limit)
-        assert run_kmeans_fits.lds_fits - before == len(fits)
+    for slots in (5, 4096):
+        got = run_kmeans_fits(hip, fits, path="fit", n_slots=slots)
         for g, f in zip(got, fits):
             assert g["labels"] == f["labels"]
             assert g["inertia_hex"] == f["inertia"]
@@ -84,8 +82,8 @@ def test_empty_cluster_relocation_on_gpu(hip):
     from tests.test_kmeans_relocation import check, degenerate_fits
     fits = degenerate_fits(8, 80)
     check(hip, fits)
-    check(hip, fits, path="lds")
-    check(hip, fits, path="lds", lds_limit=12000)
+    check(hip, fits, path="fit", n_slots=3)
+    check(hip, fits, path="fit", n_slots=1024)
 
 
 def test_batched_reentry_below_existing_nodes_on_gpu(hip):

@@ -21,8 +21,8 @@ def degenerate_fits(seed, n):
     return fits
 
 
-def check(backend, fits, path="global", lds_limit=None):
-    got = run_kmeans_fits(backend, fits, path=path, lds_limit=lds_limit)
+def check(backend, fits, path="global", n_slots=3):
+    got = run_kmeans_fits(backend, fits, path=path, n_slots=n_slots)
     for g, f in zip(got, fits):
         assert g["status"] & 1 and not g["status"] & 2
         assert g["labels"] == f["labels"]
@@ -34,10 +34,10 @@ def test_relocation_matches_oracle():
     check(EmuBackend(), degenerate_fits(7, 60))
 
 
-def test_relocation_matches_oracle_lds_path():
+def test_relocation_matches_oracle_persistent_workgroups():
     fits = degenerate_fits(7, 60)
-    check(EmuBackend(), fits, path="lds")
-    check(EmuBackend(), fits, path="lds", lds_limit=12000)        # restarts in several passes
+    check(EmuBackend(), fits, path="fit", n_slots=2)              # many fits per workgroup, one scratch slot each
+    check(EmuBackend(), fits, path="fit", n_slots=512)
 
 
 def test_fits_with_many_samples():
@@ -50,8 +50,8 @@ def test_fits_with_many_samples():
         lab, dbg = orc.kmeans_fit_predict(M, k, want_debug=True)
         fits.append(dict(shape=[D, V], counts_i16_hex=M.astype("<i2").tobytes().hex(), k=k, labels=lab.tolist(),
                          inertia=float(dbg["inertia"]).hex(), n_iter=dbg["n_iter"]))
-    for path, limit in (("global", None), ("lds", None), ("lds", 60000)):
-        got = run_kmeans_fits(EmuBackend(), fits, path=path, lds_limit=limit)
+    for path, slots in (("global", 0), ("fit", 1), ("fit", 64)):
+        got = run_kmeans_fits(EmuBackend(), fits, path=path, n_slots=slots)
         for g, f in zip(got, fits):
             assert not g["status"] & 2
             assert g["labels"] == f["labels"] and g["inertia_hex"] == f["inertia"] and g["n_iter"] == f["n_iter"]

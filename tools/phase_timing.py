@@ -24,10 +24,7 @@ eng.run_forest()
 be.synchronize()
 be.lib.mprg_debug_phase_cycles(out, 0)
 c = np.array(list(out), dtype=np.float64)
-lds_names = ["load into LDS", "k-means++ pick", "k-means++ score", "first centres", "centre-centre distances",
-             "sample-centre distances", "init bounds / E-step", "M-step", "shifts + norms", "bounds + stop test", "inertia",
-             "best restart", "predict"]
-names = lds_names if (F.KMEANS_LDS and eng.counters.get("fits_lds")) else ["k-means++ first centre", "k-means++ further centres", "centre-centre distances", "sample-centre distances",
+names = ["k-means++ first centre", "k-means++ further centres", "centre-centre distances", "sample-centre distances",
          "init bounds / E-step", "M-step sums", "cluster sizes / relocation", "average centres", "shift, bounds, stop test",
          "inertia"]
 for nm, v in zip(names, c):
