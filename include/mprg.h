@@ -158,7 +158,8 @@ int mprg_kmeans_restarts(const int64_t *prob, const int32_t *kinfo, int n_fits, 
 int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *xcounts,
                        double *ws, int32_t *labels, double *km_info, void *stream);
 /* A11, restarts + select as ONE launch of persistent workgroups (the throughput form): at most n_slots workgroups, each
- * taking fits b, b + n_slots, ... and keeping the per-restart arrays of its current fit in its own scratch slot
+ * taking the next unclaimed fit (next_fit: one int32 of device scratch, zeroed by the call; list the biggest fits first)
+ * and keeping the per-restart arrays of its current fit in its own scratch slot
  * (slot_ws + b * slot_stride_doubles; slot_stride_doubles >= n_init * mprg_kmeans_workspace_doubles' per-restart part for
  * every fit of the launch, i.e. (mprg_kmeans_workspace_doubles(D, V, k_max, n_init) - mprg_kmeans_workspace_doubles(D, V,
  * k_max, 0))).  The problems' workspaces (`ws`, prob[WS_OFF]) then only need their common part
@@ -166,9 +167,7 @@ int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, in
  * mprg_kmeans_restarts + mprg_kmeans_select; kinfo field 2 is ignored. */
 int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
                     const double *xcounts, double *ws, double *slot_ws, int64_t slot_stride_doubles, int n_slots,
-                    int32_t *labels, double *km_info, int32_t *km_status, void *stream);
-/* labels of accepted fits -> the problems' assignment (read by mprg_split_children) */
-int mprg_commit_labels(const int64_t *prob, int n_probs, const int32_t *labels, int32_t *assign, void *stream);
+                    int32_t *next_fit, int32_t *labels, double *km_info, int32_t *km_status, void *stream);
 /* fills out[n] with numpy.random.RandomState(seed).random_sample(n) (host memory; MT19937) */
 void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
 

@@ -147,13 +147,14 @@ int mprg_kmeans_restarts(const int64_t *prob, const int32_t *kinfo, int n_fits, 
 
 int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
                     const double *xcounts, double *ws, double *slot_ws, int64_t slot_stride_doubles, int n_slots,
-                    int32_t *labels, double *km_info, int32_t *km_status, void *stream) {
+                    int32_t *next_fit, int32_t *labels, double *km_info, int32_t *km_status, void *stream) {
   if (n_fits <= 0) return 0;
   if (n_init > KM_RMAX) return fail("n_init must be <= 16");
   if (n_slots <= 0 || slot_stride_doubles <= 0) return fail("mprg_kmeans_fit: no scratch slots");
+  if (hipMemsetAsync(next_fit, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return fail("memset");
   const int grid = n_fits < n_slots ? n_fits : n_slots;
   LAUNCH(k_kmeans_fit, grid, env_threads("MPRG_KM_THREADS", 256), stream, prob, kinfo, n_fits, n_init, uniforms_dev, xcounts, ws,
-         slot_ws, (long long)slot_stride_doubles, labels, km_info, km_status);
+         slot_ws, (long long)slot_stride_doubles, next_fit, labels, km_info, km_status);
   return check_launch("k_kmeans_fit");
 }
 
@@ -162,12 +163,6 @@ int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, in
   if (n_fits <= 0) return 0;
   LAUNCH(k_kmeans_select, n_fits, 256, stream, prob, kinfo, n_init, xcounts, ws, labels, km_info);
   return check_launch("k_kmeans_select");
-}
-
-int mprg_commit_labels(const int64_t *prob, int n_probs, const int32_t *labels, int32_t *assign, void *stream) {
-  if (n_probs <= 0) return 0;
-  LAUNCH(k_commit_labels, n_probs, 64, stream, prob, labels, assign);
-  return check_launch("k_commit_labels");
 }
 
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,

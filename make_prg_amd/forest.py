@@ -23,10 +23,11 @@ from .msa import CODE_GAP, decode
 
 KIND_LEAF, KIND_INTERVAL, KIND_CLUSTER = 0, 1, 2
 FUSED_VIEWS = os.environ.get("MPRG_FUSED_VIEWS", "1") != "0"     # fused small-view launch shape of mprg_partition
-# KMeans fits as one launch of persistent workgroups with per-workgroup scratch slots (mprg_kmeans_fit); fits whose
-# per-restart arrays exceed SLOT_MAX_DOUBLES take mprg_kmeans_restarts + mprg_kmeans_select (one region per problem)
-KMEANS_SLOTS = os.environ.get("MPRG_KMEANS_SLOTS", "1") != "0"
-SLOT_MAX_DOUBLES = 1 << 16                                       # 512 KiB of scratch per resident workgroup
+# KMeans fits run as launches of persistent workgroups with per-workgroup scratch slots (mprg_kmeans_fit).  Two size classes
+# per round: slots of up to SLOT_SMALL_DOUBLES (512 KiB; ~1 000 workgroups resident) and, for the few bigger fits, as many
+# slots of the class's largest need as SLOT_BUDGET_DOUBLES (2 GiB) holds.
+SLOT_SMALL_DOUBLES = 1 << 16
+SLOT_BUDGET_DOUBLES = 1 << 28
 SLOT_WGS_PER_CU = 4                                              # k_kmeans_fit: 256 threads, 4 waves per SIMD
 _ACGT = np.frombuffer(b"ACGT-RYKMSWN????", dtype=np.uint8)
 
@@ -77,7 +78,6 @@ class _Offset:
 
 class ForestEngine(BatchEngine):
     """load() as BatchEngine; run_forest() builds every tree of the batch; assemble_prgs() emits the PRG strings."""
-    k_slots = 1          # k values fitted per round; >1 fits k, k+1, .. speculatively in one launch (measured: no gain)
 
     # ------------------------------------------------------------------------------------------------ device row pool
     def _pool_reserve(self, extra_rows: int):
@@ -315,18 +315,15 @@ class ForestEngine(BatchEngine):
         be.call("mprg_kmer_dictionary", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
                 be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), be.stream)
         V = be.download(d_V, np.int32, P).astype(np.int64)
-        NS = self.k_slots                                      # k values fitted per round (speculation depth)
-        # per-restart arrays: scratch slots of the persistent workgroups for the fits that fit one (the rule) — their
-        # problems then need the common workspace only — else one region per problem behind the common part
-        rdoubles = N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)                  # mprg_kmeans_workspace_doubles, restart part
-        self._slot_ok = (rdoubles <= SLOT_MAX_DOUBLES) & (NS == 1) & KMEANS_SLOTS
-        self._rdoubles = rdoubles
-        wsz = D * V + 2 * V + D + 8 + 3 * D * D + np.where(self._slot_ok, 0, NS * rdoubles)
+        # the per-restart arrays live in the scratch slots of the persistent workgroups (mprg_kmeans_fit): a problem's
+        # workspace holds its common part only (centred matrix, norms, k-means++ tables)
+        self._rdoubles = N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)           # mprg_kmeans_workspace_doubles, restart part
+        wsz = D * V + 2 * V + D + 8 + 3 * D * D
         ptab[:, 7], ptab[:, 8], ptab[:, 9], ptab[:, 10] = V, _excl_cumsum(D * V), _excl_cumsum(wsz), so
         lo = int(D.sum())
         d_ptab = be.upload(ptab)
         d_x, d_ws = be.zeros(8 * int((D * V).sum())), be.empty(8 * int(wsz.sum()))
-        d_labels, d_assign = be.empty(4 * lo * NS), be.zeros(4 * lo)
+        d_labels, d_assign = be.empty(4 * lo), be.zeros(4 * lo)
         be.call("mprg_kmer_counts", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
                 be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_x), be.stream)
         self._kmeans_prepare(d_ptab, D, V, d_x, d_ws)
@@ -336,15 +333,11 @@ class ForestEngine(BatchEngine):
         for k_, o_ in uoff.items():
             uoff_arr[k_] = o_
 
-        # cluster_sequences.py:256-274 for all problems of the level, NS values of k per round: the fits of k, k+1, ...
-        # of a problem are independent (every KMeans() starts from a fresh RandomState(2)), so they run in ONE launch;
-        # the host then replays the reference's sequential decisions over the results and discards fits made in vain.
+        # cluster_sequences.py:256-274 for all problems of the level, one k per round
         num_clusters = np.ones(P, np.int64)
         active = np.argsort(-(D * V), kind="stable")            # biggest fits first: the grid's tail is its largest problem
-        kmax = np.minimum(MAX_CLUSTERS, D - 1)                  # k == D stops the loop before a fit (:260-261)
-        k_base = 2
         k = 1
-        while NS == 1 and len(active):                          # one k per round: the reference's loop as it stands
+        while len(active):                                      # one k per round: the reference's loop as it stands
             k += 1
             num_clusters[active] += 1
             active = active[(num_clusters[active] <= MAX_CLUSTERS) & (num_clusters[active] != D[active])]
@@ -364,84 +357,6 @@ class ForestEngine(BatchEngine):
             if len(active):                                      # also commits the accepted labels
                 active = active[self._cluster_further(d_sub, d_rowidx, sub, ptab[active], k, dd["d_of_row"], d_labels,
                                                       d_assign, d_scratch, d_further)]
-        while NS > 1 and len(active) and k_base <= MAX_CLUSTERS:
-            ks = [k for k in range(k_base, min(k_base + NS, MAX_CLUSTERS + 1))]
-            ent_prob, ent_k, ent_slot = [], [], []
-            for s_, k in enumerate(ks):
-                el = active[kmax[active] >= k]
-                ent_prob.append(el); ent_k.append(np.full(len(el), k)); ent_slot.append(np.full(len(el), s_))
-            ent_prob, ent_k, ent_slot = np.concatenate(ent_prob), np.concatenate(ent_k), np.concatenate(ent_slot)
-            nF = len(ent_prob)
-            if nF:
-                ki = np.empty((nF, 5), np.int32)
-                ki[:, 0], ki[:, 1], ki[:, 2] = ent_prob, ent_k, ent_slot * N_INIT
-                ki[:, 3], ki[:, 4] = uoff_arr[ent_k], ent_slot * lo
-                d_ki, d_st, d_info = be.upload(ki), be.zeros(4 * nF), be.empty(64 * nF)
-                be.call("mprg_kmeans_restarts", be.ptr(d_ptab), be.ptr(d_ki), nF, N_INIT, be.ptr(d_uni), be.ptr(d_ws),
-                        be.ptr(d_st), be.stream)
-                be.call("mprg_kmeans_select", be.ptr(d_ptab), be.ptr(d_ki), nF, N_INIT, be.ptr(d_x), be.ptr(d_ws),
-                        be.ptr(d_labels), be.ptr(d_info), be.stream)
-                self.counters["launches"] += 2
-                # cluster_further of every fit, slot by slot (labels of slot s live at d_labels + s*lo)
-                further = np.zeros(nF, bool)
-                for s_, k in enumerate(ks):
-                    m = np.nonzero(ent_slot == s_)[0]
-                    if len(m):
-                        further[m] = self._cluster_further(d_sub, d_rowidx, sub, ptab[ent_prob[m]], k, dd["d_of_row"],
-                                                           _Offset(be, d_labels, 4 * lo * s_), None, d_scratch, d_further)
-                st = be.download(d_st, np.int32, nF)
-                info = be.download(d_info, np.float64, 8 * nF).reshape(nF, 8)
-                if (st & 2).any():
-                    raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
-                                    "is not restated on the device; refusing to continue with a possibly different result")
-            # replay the reference's loop over this round's k values
-            done = np.zeros(P, bool)
-            acc_slot = np.full(P, -1, np.int64)
-            ent_of = {}                                          # (slot) -> entry index per problem
-            for s_, k in enumerate(ks):
-                cand = np.zeros(P, bool)
-                cand[active] = True
-                cand &= ~done
-                num_clusters[cand] += 1
-                over = cand & ((num_clusters > MAX_CLUSTERS) | (num_clusters == D))
-                done |= over
-                cand &= ~over
-                if not cand.any():
-                    continue
-                m = np.nonzero(ent_slot == s_)[0]
-                e_of_p = np.full(P, -1, np.int64)
-                e_of_p[ent_prob[m]] = m
-                ce = e_of_p[cand]                                # every candidate has a fit in this slot
-                pidx = np.nonzero(cand)[0]
-                used = ce >= 0
-                pidx, ce = pidx[used], ce[used]
-                kb = float((8.0 * D[pidx] * V[pidx] * (info[ce, 4] + N_INIT)).sum())
-                self.counters["fits"] += len(pidx)
-                self.counters["kmeans_bytes"] += kb
-                bad = info[ce, 3].astype(np.int64) < k           # cluster_sequences.py:267-273: revert and stop
-                num_clusters[pidx[bad]] -= 1
-                done[pidx[bad]] = True
-                good_p, good_e = pidx[~bad], ce[~bad]
-                acc_slot[good_p] = s_
-                done[good_p[~further[good_e]]] = True
-            # commit the labels of each problem's last accepted fit of this round
-            for s_ in range(len(ks)):
-                cp = np.nonzero(acc_slot == s_)[0]
-                if len(cp):
-                    d_cp = be.upload(ptab[cp])
-                    be.call("mprg_commit_labels", be.ptr(d_cp), len(cp), be.ptr(_Offset(be, d_labels, 4 * lo * s_)),
-                            be.ptr(d_assign), be.stream)
-                    self.counters["launches"] += 1
-            if be.profile is not None and be.profile.get("mprg_kmeans_restarts") and nF:
-                a0, a1, _ = be.profile["mprg_kmeans_restarts"][-1]
-                be.profile["mprg_kmeans_restarts"][-1] = (a0, a1, float((8.0 * D[ent_prob] * V[ent_prob] * (info[:, 4] + N_INIT)).sum()))
-            active = active[~done[active]]
-            k_base += NS
-        # the reference leaves num_clusters at 11 when the loop ends by exceeding MAX_CLUSTERS (:258-259)
-        if NS > 1:
-            still = active
-            num_clusters[still] = np.where(num_clusters[still] >= MAX_CLUSTERS, MAX_CLUSTERS + 1, num_clusters[still])
-
         # ---- MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
         splits = np.nonzero((num_clusters != 1) & (num_clusters != D))[0]
         if not len(splits):
@@ -476,41 +391,38 @@ class ForestEngine(BatchEngine):
 
     # ------------------------------------------------------------------------------------------------ KMeans rounds
     def _kmeans_round(self, active, k, D, V, uoff, d_ptab, d_uni, d_x, d_ws, d_labels):
-        """One k of the reference's loop (cluster_sequences.py:262-266) for the problems `active`: one mprg_kmeans_fit launch
-        (persistent workgroups, scratch slots, selection fused) for the fits whose per-restart arrays fit a slot, the
-        two-launch form for the others.  Returns (active reordered by launch, status, km_info rows)."""
+        """One k of the reference's loop (cluster_sequences.py:262-266) for the problems `active`: mprg_kmeans_fit launches
+        (persistent workgroups, scratch slots, selection fused) — one for the fits whose per-restart arrays fit a small
+        slot (the rule: ~1 000 resident workgroups), one with fewer, bigger slots for the rest.
+        Returns (active reordered by launch, status, km_info rows)."""
         be = self.be
-        slot = self._slot_ok[active]
-        order = np.lexsort((-(D[active] * V[active]), ~slot))            # slot fits first, biggest first inside each form
-        active, slot = active[order], slot[order]
-        nA, n_slot = len(active), int(slot.sum())
+        small = self._rdoubles[active] <= SLOT_SMALL_DOUBLES
+        order = np.lexsort((-(D[active] * V[active]), ~small))          # small-slot fits first, biggest first inside each class
+        active, small = active[order], small[order]
+        nA, n_small = len(active), int(small.sum())
         ki = np.empty((nA, 5), np.int32)
         ki[:, 0], ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = active, k, 0, uoff, 0
-        d_ki, d_st, d_info = be.upload(ki), be.zeros(4 * nA), be.empty(64 * nA)
-        timed = []                                                      # (entry point, its event slot, rows) when profiling
-        if n_slot:
-            stride = int(self._rdoubles[active[:n_slot]].max())
-            n_slots = min(n_slot, SLOT_WGS_PER_CU * be.n_cus)
+        d_ki, d_st, d_info, d_next = be.upload(ki), be.zeros(4 * nA), be.empty(64 * nA), be.empty(16)
+        timed = []                                                      # (its event slot, rows) when profiling
+        for lo, hi in ((0, n_small), (n_small, nA)):
+            n = hi - lo
+            if not n:
+                continue
+            stride = int(self._rdoubles[active[lo:hi]].max())
+            n_slots = max(1, min(n, SLOT_WGS_PER_CU * be.n_cus, SLOT_BUDGET_DOUBLES // stride))
             d_slots = be.empty(8 * stride * n_slots)
-            be.call("mprg_kmeans_fit", be.ptr(d_ptab), be.ptr(d_ki), n_slot, N_INIT, be.ptr(d_uni), be.ptr(d_x), be.ptr(d_ws),
-                    be.ptr(d_slots), stride, n_slots, be.ptr(d_labels), be.ptr(d_info), be.ptr(d_st), be.stream)
+            off = lambda buf, b: _Offset(be, buf, b * lo)
+            be.call("mprg_kmeans_fit", be.ptr(d_ptab), be.ptr(off(d_ki, 20)), n, N_INIT, be.ptr(d_uni), be.ptr(d_x), be.ptr(d_ws),
+                    be.ptr(d_slots), stride, n_slots, be.ptr(d_next), be.ptr(d_labels), be.ptr(off(d_info, 64)),
+                    be.ptr(off(d_st, 4)), be.stream)
             self.counters["launches"] += 1
             if be.profile is not None and be.profile.get("mprg_kmeans_fit"):
-                timed.append(("mprg_kmeans_fit", len(be.profile["mprg_kmeans_fit"]) - 1, slice(0, n_slot)))
-        if n_slot < nA:
-            n, off = nA - n_slot, lambda buf, b: _Offset(be, buf, b * n_slot)
-            be.call("mprg_kmeans_restarts", be.ptr(d_ptab), be.ptr(off(d_ki, 20)), n, N_INIT, be.ptr(d_uni), be.ptr(d_ws),
-                    be.ptr(off(d_st, 4)), be.stream)
-            be.call("mprg_kmeans_select", be.ptr(d_ptab), be.ptr(off(d_ki, 20)), n, N_INIT, be.ptr(d_x), be.ptr(d_ws),
-                    be.ptr(d_labels), be.ptr(off(d_info, 64)), be.stream)
-            self.counters["launches"] += 2
-            if be.profile is not None and be.profile.get("mprg_kmeans_restarts"):
-                timed.append(("mprg_kmeans_restarts", len(be.profile["mprg_kmeans_restarts"]) - 1, slice(n_slot, nA)))
+                timed.append((len(be.profile["mprg_kmeans_fit"]) - 1, slice(lo, hi)))
         st = be.download(d_st, np.int32, nA)
         info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
-        for name, ev, rows in timed:         # algorithmic bytes are known only after the fits: 8 D V (Elkan iterations + n_init)
-            a0, a1, _ = be.profile[name][ev]
-            be.profile[name][ev] = (a0, a1, float((8.0 * D[active[rows]] * V[active[rows]] * (info[rows, 4] + N_INIT)).sum()))
+        for ev, rows in timed:               # algorithmic bytes are known only after the fits: 8 D V (Elkan iterations + n_init)
+            a0, a1, _ = be.profile["mprg_kmeans_fit"][ev]
+            be.profile["mprg_kmeans_fit"][ev] = (a0, a1, float((8.0 * D[active[rows]] * V[active[rows]] * (info[rows, 4] + N_INIT)).sum()))
         return active, st, info
 
     # ------------------------------------------------------------------------------------------------ tables

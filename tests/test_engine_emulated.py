@@ -32,14 +32,6 @@ def test_node_object_host_matches_too(emu, golden_integration, golden_synthetic,
     assert pc.check_synthetic(emu, golden_synthetic, configs=("B",), limit=12) == 12
 
 
-def test_speculative_k_rounds_give_the_same_trees(emu, golden_synthetic, monkeypatch):
-    """forest.ForestEngine.k_slots > 1 fits several k per launch and replays the reference's decisions afterwards."""
-    from make_prg_amd.forest import ForestEngine
-    monkeypatch.setattr(ForestEngine, "k_slots", 3)
-    assert pc.check_synthetic(emu, golden_synthetic, configs=("B",), limit=16) == 16
-    assert pc.check_synthetic(emu, golden_synthetic, configs=("C",), limit=3) == 3
-
-
 def test_load_time_consensus_counts_from_the_device(emu):
     """mprg_column_residue_counts + the host's seeded choice == the host-only majority consensus (reference
     utils/seq_utils.py:246-290), on alignments with many N, ties, lower case, ambiguity codes and all-N columns."""
