@@ -23,10 +23,13 @@ from .msa import CODE_GAP, decode
 
 KIND_LEAF, KIND_INTERVAL, KIND_CLUSTER = 0, 1, 2
 FUSED_VIEWS = os.environ.get("MPRG_FUSED_VIEWS", "1") != "0"     # fused small-view launch shape of mprg_partition
-# KMeans fits run as launches of persistent workgroups with per-workgroup scratch slots (mprg_kmeans_fit).  Two size classes
-# per round: slots of up to SLOT_SMALL_DOUBLES (512 KiB; ~1 000 workgroups resident) and, for the few bigger fits, as many
-# slots of the class's largest need as SLOT_BUDGET_DOUBLES (2 GiB) holds.
-SLOT_SMALL_DOUBLES = 1 << 16
+# KMeans fits run as launches of persistent workgroups with per-workgroup scratch slots (mprg_kmeans_fit).  One launch per
+# round as long as a full set of resident workgroups (4 per CU) with slots of the round's largest need stays inside
+# SLOT_BUDGET_DOUBLES (2 GiB; a slot is touched only as far as its current fit needs); fits beyond SLOT_SMALL_DOUBLES
+# (2 MiB per slot: config D, Ddeep) get a launch of their own with as many slots as the budget holds.
+# MPRG_KMEANS_SLOTS=0 (measurement switch): the two-launch form with one restart region per problem instead.
+KMEANS_SLOTS = os.environ.get("MPRG_KMEANS_SLOTS", "1") != "0"
+SLOT_SMALL_DOUBLES = 1 << 18
 SLOT_BUDGET_DOUBLES = 1 << 28
 SLOT_WGS_PER_CU = 4                                              # k_kmeans_fit: 256 threads, 4 waves per SIMD
 _ACGT = np.frombuffer(b"ACGT-RYKMSWN????", dtype=np.uint8)
@@ -318,7 +321,7 @@ class ForestEngine(BatchEngine):
         # the per-restart arrays live in the scratch slots of the persistent workgroups (mprg_kmeans_fit): a problem's
         # workspace holds its common part only (centred matrix, norms, k-means++ tables)
         self._rdoubles = N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)           # mprg_kmeans_workspace_doubles, restart part
-        wsz = D * V + 2 * V + D + 8 + 3 * D * D
+        wsz = D * V + 2 * V + D + 8 + 3 * D * D + (0 if KMEANS_SLOTS else self._rdoubles)
         ptab[:, 7], ptab[:, 8], ptab[:, 9], ptab[:, 10] = V, _excl_cumsum(D * V), _excl_cumsum(wsz), so
         lo = int(D.sum())
         d_ptab = be.upload(ptab)
@@ -404,7 +407,12 @@ class ForestEngine(BatchEngine):
         ki[:, 0], ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = active, k, 0, uoff, 0
         d_ki, d_st, d_info, d_next = be.upload(ki), be.zeros(4 * nA), be.empty(64 * nA), be.empty(16)
         timed = []                                                      # (its event slot, rows) when profiling
-        for lo, hi in ((0, n_small), (n_small, nA)):
+        if not KMEANS_SLOTS:
+            be.call("mprg_kmeans_restarts", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_uni), be.ptr(d_ws), be.ptr(d_st), be.stream)
+            be.call("mprg_kmeans_select", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_labels),
+                    be.ptr(d_info), be.stream)
+            self.counters["launches"] += 2
+        for lo, hi in (((0, n_small), (n_small, nA)) if KMEANS_SLOTS else ()):
             n = hi - lo
             if not n:
                 continue
