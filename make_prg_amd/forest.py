@@ -23,12 +23,15 @@ from .msa import CODE_GAP, decode
 
 KIND_LEAF, KIND_INTERVAL, KIND_CLUSTER = 0, 1, 2
 FUSED_VIEWS = os.environ.get("MPRG_FUSED_VIEWS", "1") != "0"     # fused small-view launch shape of mprg_partition
-# KMeans fits run as launches of persistent workgroups with per-workgroup scratch slots (mprg_kmeans_fit).  One launch per
-# round as long as a full set of resident workgroups (4 per CU) with slots of the round's largest need stays inside
-# SLOT_BUDGET_DOUBLES (2 GiB; a slot is touched only as far as its current fit needs); fits beyond SLOT_SMALL_DOUBLES
-# (2 MiB per slot: config D, Ddeep) get a launch of their own with as many slots as the budget holds.
-# MPRG_KMEANS_SLOTS=0 (measurement switch): the two-launch form with one restart region per problem instead.
-KMEANS_SLOTS = os.environ.get("MPRG_KMEANS_SLOTS", "1") != "0"
+# KMeans rounds: mprg_kmeans_restarts + mprg_kmeans_select with one restart region per problem (default), or — with
+# MPRG_KMEANS_SLOTS=1 — mprg_kmeans_fit: persistent workgroups that claim fits and keep the per-restart arrays in their own
+# scratch slot, selection fused.  Measured on one MI355X, same box (profiles/r02/kmeans_forms.md): exclusive pass 47.7 ms
+# (two launches) against 53.6 ms (persistent) per 3 000 alignments; ten workers 36.3 k against 37.3 k MSAs/s (within the
+# run-to-run noise); HBM-side traffic 2.3x against 3.0x the algorithmic bytes.  The persistent form needs 0.5 GB of scratch
+# instead of ~3 GB of restart regions per level and worker.  One launch per round as long as a full set of resident
+# workgroups (4 per CU) with slots of the round's largest need stays inside SLOT_BUDGET_DOUBLES (2 GiB); fits beyond
+# SLOT_SMALL_DOUBLES (2 MiB per slot: config D, Ddeep) get a launch of their own with as many slots as the budget holds.
+KMEANS_SLOTS = os.environ.get("MPRG_KMEANS_SLOTS", "0") != "0"
 SLOT_SMALL_DOUBLES = 1 << 18
 SLOT_BUDGET_DOUBLES = 1 << 28
 SLOT_WGS_PER_CU = 4                                              # k_kmeans_fit: 256 threads, 4 waves per SIMD
