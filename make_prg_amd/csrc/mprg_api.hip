@@ -105,7 +105,7 @@ int mprg_kmer_dictionary(const int64_t *views, const int64_t *prob, int n_probs,
   (void)ulen;
   if (n_probs <= 0) return 0;
   if (kmer_size < 1 || kmer_size > 16) return fail("k-mer size must be in 1..16 (4-bit packed keys)");
-  LAUNCH(k_kmer_dictionary, n_probs, 512, stream, views, prob, kmer_size, ucodes, seqrow, (const int64_t *)occ_off, table,
+  LAUNCH(k_kmer_dictionary, n_probs, KD_THREADS, stream, views, prob, kmer_size, ucodes, seqrow, (const int64_t *)occ_off, table,
          first_flag, out_V);
   return check_launch("k_kmer_dictionary");
 }
