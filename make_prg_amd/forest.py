@@ -397,9 +397,10 @@ class ForestEngine(BatchEngine):
 
     # ------------------------------------------------------------------------------------------------ KMeans rounds
     def _kmeans_round(self, active, k, D, V, uoff, d_ptab, d_uni, d_x, d_ws, d_labels):
-        """One k of the reference's loop (cluster_sequences.py:262-266) for the problems `active`: mprg_kmeans_fit launches
-        (persistent workgroups, scratch slots, selection fused) — one for the fits whose per-restart arrays fit a small
-        slot (the rule: ~1 000 resident workgroups), one with fewer, bigger slots for the rest.
+        """One k of the reference's loop (cluster_sequences.py:262-266) for the problems `active`.  Default form:
+        mprg_kmeans_restarts (one workgroup per fit and restart) + mprg_kmeans_select.  With MPRG_KMEANS_SLOTS=1:
+        mprg_kmeans_fit (persistent workgroups, scratch slots, selection fused) — one launch for the fits whose
+        per-restart arrays fit a small slot (~1 000 resident workgroups), one with fewer, bigger slots for the rest.
         Returns (active reordered by launch, status, km_info rows)."""
         be = self.be
         small = self._rdoubles[active] <= SLOT_SMALL_DOUBLES
@@ -409,9 +410,15 @@ class ForestEngine(BatchEngine):
         ki = np.empty((nA, 5), np.int32)
         ki[:, 0], ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = active, k, 0, uoff, 0
         d_ki, d_st, d_info, d_next = be.upload(ki), be.zeros(4 * nA), be.empty(64 * nA), be.empty(16)
-        timed = []                                                      # (its event slot, rows) when profiling
+        timed = []                                                      # (entry point, its event slot, rows) when profiling
+
+        def mark(name, rows):
+            if be.profile is not None and be.profile.get(name):
+                timed.append((name, len(be.profile[name]) - 1, rows))
+
         if not KMEANS_SLOTS:
             be.call("mprg_kmeans_restarts", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_uni), be.ptr(d_ws), be.ptr(d_st), be.stream)
+            mark("mprg_kmeans_restarts", slice(0, nA))
             be.call("mprg_kmeans_select", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_labels),
                     be.ptr(d_info), be.stream)
             self.counters["launches"] += 2
@@ -427,13 +434,12 @@ class ForestEngine(BatchEngine):
                     be.ptr(d_slots), stride, n_slots, be.ptr(d_next), be.ptr(d_labels), be.ptr(off(d_info, 64)),
                     be.ptr(off(d_st, 4)), be.stream)
             self.counters["launches"] += 1
-            if be.profile is not None and be.profile.get("mprg_kmeans_fit"):
-                timed.append((len(be.profile["mprg_kmeans_fit"]) - 1, slice(lo, hi)))
+            mark("mprg_kmeans_fit", slice(lo, hi))
         st = be.download(d_st, np.int32, nA)
         info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
-        for ev, rows in timed:               # algorithmic bytes are known only after the fits: 8 D V (Elkan iterations + n_init)
-            a0, a1, _ = be.profile["mprg_kmeans_fit"][ev]
-            be.profile["mprg_kmeans_fit"][ev] = (a0, a1, float((8.0 * D[active[rows]] * V[active[rows]] * (info[rows, 4] + N_INIT)).sum()))
+        for name, ev, rows in timed:         # algorithmic bytes are known only after the fits: 8 D V (Elkan iterations + n_init)
+            a0, a1, _ = be.profile[name][ev]
+            be.profile[name][ev] = (a0, a1, float((8.0 * D[active[rows]] * V[active[rows]] * (info[rows, 4] + N_INIT)).sum()))
         return active, st, info
 
     # ------------------------------------------------------------------------------------------------ tables
