@@ -212,6 +212,7 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1):
             elif cmd == "e2e":
                 conn.send(("done", end_to_end()))
             else:
+                pool.shutdown(wait=True)
                 return
     except BaseException as err:        # the parent must hear about it: there is no silent fallback
         import traceback
@@ -277,7 +278,7 @@ def main():
         W = max(1, min(W, max(1, (ncpu - 1) // max(world, 1)), int(avail_kib / (4 << 20) / 4 / max(world, 1))))
     seeds = list(range(args.batch))           # the same alignments on every rank: each rank's work is verifiable
     gen_procs = args.gen_procs or max(1, min(16, ncpu // (max(W, 1) * max(world, 1))))
-    conns, procs = [], []
+    conns, procs, th = [], [], None
     for w in range(W):
         a, b = ctx.Pipe()
         pr = ctx.Process(target=_worker, args=(b, local_rank, seeds[w::W], args.streams, gen_procs))
@@ -447,6 +448,8 @@ def main():
         print(json.dumps(out))
     for pr in procs:
         pr.join(timeout=30)
+    if th is not None:
+        th.join(timeout=30)
     if world > 1:
         dist.destroy_process_group()
     if verified is not None and (verified["mismatches"] or verified.get("mismatches_all_ranks", 0)):

@@ -29,7 +29,7 @@ static int check_launch(const char *name) {
 static int env_threads(const char *name, int dflt) {
   const char *e = getenv(name);
   const int v = e ? atoi(e) : dflt;
-  return (v >= 64 && v <= 256 && v % 64 == 0) ? v : dflt;
+  return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : dflt;
 }
 
 extern "C" {
@@ -131,7 +131,10 @@ int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts,
   if (!lds_list && !other_list) { n_lds = 0; n_other = n_probs; }
   else if (n_lds + n_other != n_probs) return fail("mprg_kmeans_prepare: the two problem lists must cover the problems");
   if (n_lds > 0 && (lds_bytes <= 0 || lds_bytes > MPRG_KMEANS_PREPARE_LDS_MAX)) return fail("mprg_kmeans_prepare: lds_bytes out of range");
-  if (n_other > 0) LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws);
+  if (n_other > 0) {
+    LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws);
+    LAUNCH(k_kmeans_prepare_tables, (long long)n_other * KP_PARTS, 256, stream, other_list, prob, xcounts, ws);
+  }
   if (n_lds > 0) LAUNCH_LDS(k_kmeans_prepare_lds, n_lds, 256, lds_bytes, stream, lds_list, prob, xcounts, ws);
   return check_launch("k_kmeans_prepare");
 }

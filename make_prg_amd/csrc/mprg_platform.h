@@ -14,9 +14,9 @@
 #define MPRG_DEV __device__ __forceinline__
 #define MPRG_DEVM __device__ __forceinline__
 #define KERNEL(name, ...) __global__ void name(__VA_ARGS__)
-// at most 256 threads per workgroup (else the compiler must budget registers for 1024) and `waves` waves per SIMD
+// `waves` waves per SIMD (fixes the register budget: 512 / waves VGPRs), workgroups of up to 64 * 4 * waves threads
 #define KERNEL_OCC(name, waves, ...) \
-  __attribute__((amdgpu_flat_work_group_size(64, 256), amdgpu_waves_per_eu(waves, waves))) __global__ void name(__VA_ARGS__)
+  __attribute__((amdgpu_flat_work_group_size(64, 256 * (waves)), amdgpu_waves_per_eu(waves, waves))) __global__ void name(__VA_ARGS__)
 #define LAUNCH(name, nblocks, nthreads, stream, ...) \
   hipLaunchKernelGGL(name, dim3((unsigned)(nblocks)), dim3((unsigned)(nthreads)), 0, (hipStream_t)(stream), __VA_ARGS__)
 #define LAUNCH_LDS(name, nblocks, nthreads, lds_bytes, stream, ...) \
