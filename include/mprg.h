@@ -145,7 +145,8 @@ int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int
  * uniforms of one k: n_init * (1 + (k-1)*(2+int(ln k))) doubles of numpy RandomState(2).random_sample.
  * labels int32; km_status int32[n_fits] (MPRG_KM_*); km_info double[8*n_fits] = {inertia, n_iter of the best restart,
  * best restart, n distinct labels, total Elkan iterations, -, -, -}.
- * Workspace size per problem (doubles): mprg_kmeans_workspace_doubles(D, V, k_max, restart slots). */
+ * Workspace size per problem (doubles): mprg_kmeans_workspace_doubles(D, V, k_max, restart slots); -1 if k_max > 10 or
+ * V > 4 194 304 features (the limits of the kernels). */
 int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_restart_slots);
 /* mprg_kmeans_prepare, problem lists (both NULL: every problem takes the global-memory form): the problems of lds_list
  * (int32 rows of `prob`) stage their matrix in LDS — lds_bytes >= 8 * (D * (V | 1) + 2 * V) for each of them, at most

@@ -121,7 +121,7 @@ int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int
 }
 
 int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_restart_slots) {
-  if (k_max > KM_KMAX) return -1;
+  if (k_max > KM_KMAX || V > (128LL << (KM_PW_DEPTH - 1))) return -1;       // V: depth of the pairwise-sum stack (k_kmeans.inc)
   return km_common_doubles_host(D, V) + (int64_t)n_restart_slots * km_restart_doubles_host(D, V);
 }
 

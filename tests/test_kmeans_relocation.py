@@ -55,3 +55,23 @@ def test_fits_with_many_samples():
         for g, f in zip(got, fits):
             assert not g["status"] & 2
             assert g["labels"] == f["labels"] and g["inertia_hex"] == f["inertia"] and g["n_iter"] == f["n_iter"]
+
+
+def test_relocation_with_wide_matrices():
+    """More than 128 features: the tolerance (np.var(...).mean()) and the relocation distances take NumPy's pairwise-sum
+    recursion, which the kernels run on a stack in LDS."""
+    rng = np.random.default_rng(11)
+    fits = []
+    for V in (150, 300, 700, 1100):
+        for _ in range(200):
+            D = int(rng.integers(6, 13)); n_distinct = int(rng.integers(2, 4)); k = int(rng.integers(n_distinct + 1, min(D, 6) + 1))
+            base = rng.integers(0, 3, (n_distinct, V))
+            M = base[rng.integers(0, n_distinct, D)].astype(np.float64)
+            lab, dbg = orc.kmeans_fit_predict(M, k, want_debug=True)
+            if dbg["flags"] & 1:
+                fits.append(dict(shape=[D, V], counts_i16_hex=M.astype("<i2").tobytes().hex(), k=k, labels=lab.tolist(),
+                                 inertia=float(dbg["inertia"]).hex(), n_iter=dbg["n_iter"]))
+                break
+    assert len(fits) >= 3
+    check(EmuBackend(), fits)
+    check(EmuBackend(), fits, path="fit", n_slots=2)
