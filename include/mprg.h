@@ -155,7 +155,7 @@ enum { MPRG_KMEANS_PREPARE_LDS_MAX = 64 * 1024 };
 int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, const int32_t *lds_list,
                         int n_lds, int64_t lds_bytes, const int32_t *other_list, int n_other, void *stream);
 int mprg_kmeans_restarts(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
-                         double *ws, int32_t *km_status, void *stream);
+                         const double *xcounts, double *ws, int32_t *km_status, void *stream);
 int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *xcounts,
                        double *ws, int32_t *labels, double *km_info, void *stream);
 /* A11, restarts + select as ONE launch of persistent workgroups (the throughput form): at most n_slots workgroups, each

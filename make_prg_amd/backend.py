@@ -31,7 +31,7 @@ SIGNATURES = {
     "mprg_kmer_counts": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7),
     "mprg_kmeans_workspace_doubles": (c_int64, [c_int64, c_int64, c_int, c_int]),
     "mprg_kmeans_prepare": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p]),
-    "mprg_kmeans_restarts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mprg_kmeans_restarts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mprg_kmeans_fit": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int64, c_int] + [c_void_p] * 5),
     "mprg_kmeans_select": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 5),
     "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int] + [c_void_p] * 3),

@@ -140,11 +140,11 @@ int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts,
 }
 
 int mprg_kmeans_restarts(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
-                         double *ws, int32_t *km_status, void *stream) {
+                         const double *xcounts, double *ws, int32_t *km_status, void *stream) {
   if (n_fits <= 0) return 0;
   if (n_init > KM_RMAX) return fail("n_init must be <= 16");
-  LAUNCH(k_kmeans_restart, n_fits, env_threads("MPRG_KM_THREADS", 256), stream, prob, kinfo, n_init, uniforms_dev, ws,
-         km_status);
+  LAUNCH(k_kmeans_restart, n_fits, env_threads("MPRG_KM_THREADS", 256), stream, prob, kinfo, n_init, uniforms_dev, xcounts,
+         ws, km_status);
   return check_launch("k_kmeans_restart");
 }
 

@@ -567,7 +567,7 @@ class BatchEngine:
             km_work = [0.0]
             d_ki = be.upload(self._kinfo(nA, k))
             be.call("mprg_kmeans_restarts", be.ptr(d_sp), be.ptr(d_ki), nA, N_INIT, be.ptr(self._uniforms_all()[0]),
-                    be.ptr(d_ws), be.ptr(d_st), be.stream)
+                    be.ptr(d_x), be.ptr(d_ws), be.ptr(d_st), be.stream)
             be.call("mprg_kmeans_select", be.ptr(d_sp), be.ptr(d_ki), nA, N_INIT, be.ptr(d_x), be.ptr(d_ws),
                     be.ptr(d_labels), be.ptr(d_info), be.stream)
             self.counters["launches"] += 2

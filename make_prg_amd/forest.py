@@ -417,7 +417,8 @@ class ForestEngine(BatchEngine):
                 timed.append((name, len(be.profile[name]) - 1, rows))
 
         if not KMEANS_SLOTS:
-            be.call("mprg_kmeans_restarts", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_uni), be.ptr(d_ws), be.ptr(d_st), be.stream)
+            be.call("mprg_kmeans_restarts", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_uni), be.ptr(d_x), be.ptr(d_ws), be.ptr(d_st),
+                    be.stream)
             mark("mprg_kmeans_restarts", slice(0, nA))
             be.call("mprg_kmeans_select", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_labels),
                     be.ptr(d_info), be.stream)

@@ -46,7 +46,8 @@ def run_kmeans_fits(be, fits, n_init=10, path="global", n_slots=3):
             be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws),
                     be.ptr(d_slots), stride, n_slots, be.ptr(be.empty(16)), be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
         else:
-            be.call("mprg_kmeans_restarts", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_u), be.ptr(d_ws), be.ptr(d_st1), be.stream)
+            be.call("mprg_kmeans_restarts", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws), be.ptr(d_st1),
+                    be.stream)
             be.call("mprg_kmeans_select", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_lab),
                     be.ptr(d_info1), be.stream)
         info = be.download(d_info1, np.float64, 8 * P).reshape(P, 8)

@@ -75,3 +75,21 @@ def test_relocation_with_wide_matrices():
     assert len(fits) >= 3
     check(EmuBackend(), fits)
     check(EmuBackend(), fits, path="fit", n_slots=2)
+
+
+def test_fits_outside_the_lds_count_form():
+    """The restart kernel keeps a fit's counts as bytes in LDS when they fit (km_euclid_xl); counts above 255 and matrices
+    beyond the pool take the global-memory form — same answers."""
+    rng = np.random.default_rng(5)
+    fits = []
+    for D, V, k, top in ((24, 40, 3, 400), (120, 130, 4, 6), (14, 23, 5, 256), (31, 61, 2, 3)):
+        centres = rng.integers(0, top, (4, V))
+        M = (centres[rng.integers(0, 4, D)] + rng.integers(0, 2, (D, V))).astype(np.float64)
+        lab, dbg = orc.kmeans_fit_predict(M, k, want_debug=True)
+        fits.append(dict(shape=[D, V], counts_i16_hex=M.astype("<i2").tobytes().hex(), k=k, labels=lab.tolist(),
+                         inertia=float(dbg["inertia"]).hex(), n_iter=dbg["n_iter"]))
+    for path, slots in (("global", 0), ("fit", 2)):
+        got = run_kmeans_fits(EmuBackend(), fits, path=path, n_slots=slots)
+        for g, f in zip(got, fits):
+            assert not g["status"] & 2
+            assert g["labels"] == f["labels"] and g["inertia_hex"] == f["inertia"] and g["n_iter"] == f["n_iter"]
