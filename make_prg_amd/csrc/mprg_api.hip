@@ -81,10 +81,16 @@ int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *ro
   if (n_work_rows > 0) LAUNCH(k_gap_runs, n_work_rows, GR_ROWS, stream, arena, views, rowidx, work_rows, mask, maxrun);
   if (n_other > 0)
     LAUNCH(k_partition, n_other, BLOCK_VIEW, stream, other_list, arena, views, rowidx, mask, min_match_length, maxrun, stack,
-           ivflag, iv, n_iv, status, view_out, iv_packed, iv_count);
+           ivflag, iv, n_iv, status, view_out);
   if (n_fused > 0)
     LAUNCH(k_partition_fused, n_fused, BLOCK_VIEW, stream, fused_list, arena, views, rowidx, min_match_length, iv, n_iv, status,
-           view_out, iv_packed, iv_count);
+           view_out);
+  if (view_out) {                                  // the packed list of all triples of the call
+    if (!iv_packed || !iv_count) return fail("mprg_partition: view_out needs iv_packed and iv_count");
+    LAUNCH(k_pack_scan, 1, 1024, stream, n_views, n_iv, view_out, iv_count);
+    LAUNCH(k_pack_copy, (n_views + PK_THREADS / WAVE - 1) / (PK_THREADS / WAVE), PK_THREADS, stream, n_views, views, iv, view_out,
+           iv_packed);
+  }
   return check_launch("k_partition");
 }
 
