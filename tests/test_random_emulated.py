@@ -73,3 +73,20 @@ def test_row_grouping_is_exact_when_every_hash_collides(monkeypatch):
     monkeypatch.setattr(pc, "ENGINE", "forest")
     pc.check_vs_oracle(weak, random_cases(31, 120), 5, 7)
     pc.check_vs_oracle(weak, random_cases(32, 60), 3, 2)
+
+
+def test_more_clusters_than_the_lds_offsets_of_split_children(emu, monkeypatch):
+    """1 100 distinct sequences shorter than the k-mer size next to 40 long ones: every short one is a cluster of its own,
+    more ranks than k_split_children keeps offsets for in LDS (SC_RANKS) — the one-lane form."""
+    import itertools
+    import numpy as np
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    rng = np.random.default_rng(3)
+    rows = [f"ACGTTGCAAC{''.join(w)}------GGATCCATGA" for w in itertools.islice(itertools.product("ACGT", repeat=6), 1100)]
+    for i in range(40):
+        base = list(("ACGTACGTACGT", "TTGACCTGAATC")[i % 2])
+        base[int(rng.integers(0, 12))] = "ACGT"[int(rng.integers(0, 4))]
+        rows.append("ACGTTGCAAC" + "".join(base) + "GGATCCATGA")
+    text = "".join(f">s{i}\n{r}\n" for i, r in enumerate(rows))
+    eng = pc.check_vs_oracle(emu, [text], 5, 7)
+    assert np.bincount(eng.tab["parent"][eng.tab["parent"] >= 0]).max() > 1024      # a cluster node with > 1024 children
