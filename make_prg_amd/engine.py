@@ -22,6 +22,7 @@ MAX_CLUSTERS = 10   # from_msa/cluster_sequences.py:23
 N_INIT = 10         # scikit-learn 1.3.0 default the reference's pinned environment runs with
 ROWS_PER_CHUNK = 512
 PREPARE_LDS_MAX = 64 * 1024          # MPRG_KMEANS_PREPARE_LDS_MAX (include/mprg.h)
+PREPARE_LDS_CLASSES = (12 * 1024, 24 * 1024, PREPARE_LDS_MAX)      # one launch per class of LDS need (bytes)
 TILE_COLS = 1024
 IUPAC = {"R": "GA", "Y": "TC", "K": "GT", "M": "AC", "S": "GC", "W": "AT", "A": "A", "C": "C", "G": "G", "T": "T"}
 
@@ -392,15 +393,26 @@ class BatchEngine:
         return be.download(d_further, np.int32, nA).astype(bool)
 
     def _kmeans_prepare(self, d_ptab, D, V, d_x, d_ws):
-        """mprg_kmeans_prepare with the problems split by whether their matrix fits the LDS budget (include/mprg.h)."""
+        """mprg_kmeans_prepare with the problems split by the LDS their matrix needs (include/mprg.h): every workgroup of a
+        launch allocates the launch's lds_bytes, so the small problems (the rule) go in a launch of their own and keep
+        several workgroups per CU resident; matrices beyond the budget take the global-memory form."""
         be = self.be
         need = 8 * (D * (V | 1) + 2 * V)
-        in_lds = need <= PREPARE_LDS_MAX
-        i_l, i_o = np.nonzero(in_lds)[0].astype(np.int32), np.nonzero(~in_lds)[0].astype(np.int32)
-        d_il, d_io = be.upload(i_l), be.upload(i_o)
-        be.call("mprg_kmeans_prepare", be.ptr(d_ptab), len(D), be.ptr(d_x), be.ptr(d_ws), be.ptr(d_il), len(i_l),
-                int(need[in_lds].max()) if len(i_l) else 0, be.ptr(d_io), len(i_o), be.stream,
-                work=float((8 * D * V).sum()))
+        work = float((8 * D * V).sum())
+        lo = -1
+        for hi in PREPARE_LDS_CLASSES:
+            idx = np.nonzero((need > lo) & (need <= hi))[0].astype(np.int32)
+            lo = hi
+            if len(idx):
+                d_idx = be.upload(idx)
+                be.call("mprg_kmeans_prepare", be.ptr(d_ptab), len(idx), be.ptr(d_x), be.ptr(d_ws), be.ptr(d_idx), len(idx),
+                        int(need[idx].max()), 0, 0, be.stream, work=work)
+                work = 0.0
+        idx = np.nonzero(need > PREPARE_LDS_MAX)[0].astype(np.int32)
+        if len(idx):
+            d_idx = be.upload(idx)
+            be.call("mprg_kmeans_prepare", be.ptr(d_ptab), len(idx), be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, be.ptr(d_idx), len(idx),
+                    be.stream, work=work)
 
     def _dedupe(self, d_sub, d_rowidx, n_views: int, tot_rows: int, tot_u: int, work: float = 0.0, sub=None):
         """mprg_ungap_dedupe over the views of `d_sub`; returns the device buffers by name."""
