@@ -404,7 +404,8 @@ class ForestEngine(BatchEngine):
         Returns (active reordered by launch, status, km_info rows)."""
         be = self.be
         small = self._rdoubles[active] <= SLOT_SMALL_DOUBLES
-        order = np.lexsort((-(D[active] * V[active]), ~small))          # small-slot fits first, biggest first inside each class
+        # biggest first (the launch's tail is its largest fit); the persistent form lists its small-slot class first
+        order = np.lexsort((-(D[active] * V[active]), ~small)) if KMEANS_SLOTS else np.argsort(-(D[active] * V[active]), kind="stable")
         active, small = active[order], small[order]
         nA, n_small = len(active), int(small.sum())
         ki = np.empty((nA, 5), np.int32)
