@@ -154,6 +154,12 @@ int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_res
 enum { MPRG_KMEANS_PREPARE_LDS_MAX = 64 * 1024 };
 int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, const int32_t *lds_list,
                         int n_lds, int64_t lds_bytes, const int32_t *other_list, int n_other, void *stream);
+/* mprg_kmeans_restarts, xcounts: the count matrices mprg_kmer_counts wrote (prob[X_OFF]).  A fit whose counts fit a byte
+ * and (with the feature means) 12 KB of LDS keeps them there and forms the centred values on the fly — the same
+ * subtraction mprg_kmeans_prepare performed; NULL: every fit reads the centred matrix of the workspace.  Same results
+ * either way.  n_init <= 16.  mprg_kmeans_prepare may be called several times with disjoint lists (n_probs = n_lds +
+ * n_other of that call): hosts launch the problems in classes of LDS need, because every workgroup of a launch
+ * allocates lds_bytes. */
 int mprg_kmeans_restarts(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
                          const double *xcounts, double *ws, int32_t *km_status, void *stream);
 int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *xcounts,
