@@ -222,8 +222,8 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=30000,
                     help="alignments per GPU per step (default: the whole 30k-gene pan-genome of BASELINE.json, ~15 GB of HBM)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
