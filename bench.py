@@ -19,6 +19,11 @@ What the one JSON line holds (rank 0):
                    workers in parallel; the CPU baseline below covers the identical region
   cpu_baseline     (N=1) the oracle (CPU restatement of the reference path, `port`) on a bounded sample, all host cores
 
+Defaults: K = 10 timed steps after W = 2 warm-up steps.  The workers run their steps back to back without a barrier in
+between; they leave the start barrier in lockstep (every worker in the same phase: the GPU idles while all of them
+assemble PRG strings) and fall out of phase over the first steps, so few steps measure the transient, not the rate
+(3 steps: ~745 ms per step, 12 steps: ~670 ms on the same box, profiles/r02/README.md).
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workers P] [--streams S]
     --workers 0 runs the same loop inside this process (profiler runs: nothing forks)
 """
