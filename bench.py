@@ -41,9 +41,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DIGESTS = os.path.join(ROOT, "tests", "golden", "config_c_digests.bin")
 KERNEL_OF = {"mprg_kmeans_restarts": "k_kmeans_restart", "mprg_kmeans_fit": "k_kmeans_fit",
-             "mprg_column_masks": "k_column_masks", "mprg_partition": "k_partition (+ k_partition_fused, k_gap_runs)",
+             "mprg_column_masks": "k_column_masks", "mprg_partition": "k_partition (+ k_partition_fused, k_gap_runs, k_pack_scan, k_pack_copy)",
              "mprg_ungap_dedupe": "k_ungap_dedupe (+ k_ungap_hash)", "mprg_emit_alleles": "k_emit_alleles",
-             "mprg_cluster_further": "k_cluster_majority + k_cluster_hamming"}
+             "mprg_cluster_further": "k_cluster_majority + k_cluster_hamming",
+             "mprg_kmeans_prepare": "k_kmeans_prepare_lds (+ k_kmeans_prepare, k_kmeans_prepare_tables)"}
 
 
 def _text(seed):
@@ -413,15 +414,20 @@ def main():
         # HBM traffic of the dominant kernel: from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
         # tools/summarize_pmc.py) — counters cannot be read inside this process — and only if that summary was made from
         # exactly these kernel sources; otherwise null
-        traffic = None
+        traffic = traffic_note = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")))
             if pm.get("source_digest") == source_digest():
-                traffic = pm["kernels"][top["kernel"].split(" ")[0]]["hbm_bytes_per_launch"]
+                # the PMC passes profile a different batch (8192 alignments in one process), so their bytes per launch are
+                # not this pass's: what carries over is HBM bytes / algorithmic bytes of the entry point, measured there
+                ratio = pm["entry_points"][name]["traffic_over_algorithmic"]
+                traffic = round(ratio * top["algorithmic_bytes_per_launch"], 1)
+                traffic_note = (f"{ratio} x algorithmic bytes: (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes of {name} in the PMC "
+                                f"passes of the same sources (profiles/r02/pmc_summary.json, source_digest {pm['source_digest']})")
         except Exception:
             pass
         roof = dict(bound="hbm", kernel=top["kernel"], entry_point=name, achieved=top["achieved_GBps"] or 0.0,
-                    peak=HBM_PEAK_GBS, unit="GB/s", frac=top["frac"] or 0.0, traffic=traffic,
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=top["frac"] or 0.0, traffic=traffic, traffic_note=traffic_note,
                     avg_launch_ms=top["avg_launch_ms"], launches=top["launches"],
                     algorithmic_bytes_per_launch=top["algorithmic_bytes_per_launch"],
                     measured="exclusive pass: one worker process alone on the device, one stream, "
