@@ -324,7 +324,7 @@ class ForestEngine(BatchEngine):
         # the per-restart arrays live in the scratch slots of the persistent workgroups (mprg_kmeans_fit): a problem's
         # workspace holds its common part only (centred matrix, norms, k-means++ tables)
         self._rdoubles = N_INIT * (2 * 10 * V + 2 * D * 10 + 9 * D + 512)           # mprg_kmeans_workspace_doubles, restart part
-        wsz = D * V + 2 * V + D + 8 + 3 * D * D + (0 if KMEANS_SLOTS else self._rdoubles)
+        wsz = D * V + 2 * V + D + 8 + 4 * D * D + (0 if KMEANS_SLOTS else self._rdoubles)
         ptab[:, 7], ptab[:, 8], ptab[:, 9], ptab[:, 10] = V, _excl_cumsum(D * V), _excl_cumsum(wsz), so
         lo = int(D.sum())
         d_ptab = be.upload(ptab)
