@@ -25,7 +25,8 @@ be.synchronize()
 be.lib.mprg_debug_phase_cycles(out, 0)
 c = np.array(list(out), dtype=np.float64)
 names = ["k-means++ pick", "k-means++ score + first centres", "centre-centre distances", "sample-centre distances",
-         "init bounds / E-step", "M-step", "relocation (slow path)", "shifts + norms", "bounds + stop test", "inertia"]
+         "init bounds / E-step", "M-step", "relocation (slow path)", "shifts + norms", "bounds + stop test", "inertia",
+         "k-means++ first centre (pick of round 1)", "first centres copied + counts staged in LDS"]
 for nm, v in zip(names, c):
     print(f"{100 * v / c[:16].sum():6.1f} %  {nm}   ({v / max(eng.counters['fits'], 1):.0f} cycles per fit)")
 pn = ["column flags", "serial scan", "pass A (N rows)", "pass B (row comparison)", "merge", "packed copy", "record + atomic"]
