@@ -82,8 +82,8 @@ int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t 
  * optional (all three NULL or all three set): view_out int32[8*n_views] = {n_iv, status, type of the first interval,
  *      flags (1: some column is not one plain base, i.e. the consensus has a '*' or a gap; 2: N or ambiguity codes
  *      occur), first triple of this view in iv_packed, 0, 0, 0}; iv_packed int32[3*total_cols] = the triples of all
- *      views back to back (a view's triples are contiguous; views in order of completion); iv_count int32[1]
- *      (zeroed) = triples appended.
+ *      views back to back (a view's triples are contiguous; views in index order: their places are the exclusive prefix
+ *      sum of n_iv, laid out by two small launches after the partition kernels); iv_count int32[1] = triples in the list.
  * fused_list / other_list (both NULL, or int32 device lists that together hold 0..n_views-1): the views of fused_list
  *      are SMALL — at most 512 rows and 1024 columns, rows x pitch <= 8192 bytes (pitch = columns rounded up to 4, +4
  *      if that is an even number of words), columns / max(min_match_length - 1, 1) + 4 <= 128 — and are handled by one
