@@ -151,7 +151,7 @@ int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_res
 /* mprg_kmeans_prepare, problem lists (both NULL: every problem takes the global-memory form): the problems of lds_list
  * (int32 rows of `prob`) stage their matrix in LDS — lds_bytes >= 8 * (D * (V | 1) + 2 * V) for each of them, at most
  * MPRG_KMEANS_PREPARE_LDS_MAX — so that the ordered reductions read LDS; other_list takes the rest. */
-enum { MPRG_KMEANS_PREPARE_LDS_MAX = 64 * 1024 };
+enum { MPRG_KMEANS_PREPARE_LDS_MAX = 156 * 1024 };      /* gfx950: 160 KB of LDS per CU */
 int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, const int32_t *lds_list,
                         int n_lds, int64_t lds_bytes, const int32_t *other_list, int n_other, void *stream);
 /* mprg_kmeans_restarts, xcounts: the count matrices mprg_kmer_counts wrote (prob[X_OFF]).  A fit whose counts fit a byte

@@ -141,7 +141,18 @@ int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts,
     LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws);
     LAUNCH(k_kmeans_prepare_tables, (long long)n_other * KP_PARTS, 256, stream, other_list, prob, xcounts, ws);
   }
-  if (n_lds > 0) LAUNCH_LDS(k_kmeans_prepare_lds, n_lds, 256, lds_bytes, stream, lds_list, prob, xcounts, ws);
+  if (n_lds > 0) {
+    if (lds_bytes > 64 * 1024) {     // beyond the default per-workgroup limit: gfx950 has 160 KB of LDS per CU, one such workgroup fits
+      static bool raised = false;
+      if (!raised) {
+        if (hipFuncSetAttribute((const void *)k_kmeans_prepare_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                MPRG_KMEANS_PREPARE_LDS_MAX) != hipSuccess)
+          return fail("mprg_kmeans_prepare: the device refuses MPRG_KMEANS_PREPARE_LDS_MAX bytes of LDS per workgroup");
+        raised = true;
+      }
+    }
+    LAUNCH_LDS(k_kmeans_prepare_lds, n_lds, 256, lds_bytes, stream, lds_list, prob, xcounts, ws);
+  }
   return check_launch("k_kmeans_prepare");
 }
 

@@ -21,8 +21,8 @@ BIT_GAP, BIT_N, BITS_IUPAC = 1 << 4, 1 << 11, 0x7E0
 MAX_CLUSTERS = 10   # from_msa/cluster_sequences.py:23
 N_INIT = 10         # scikit-learn 1.3.0 default the reference's pinned environment runs with
 ROWS_PER_CHUNK = 512
-PREPARE_LDS_MAX = 64 * 1024          # MPRG_KMEANS_PREPARE_LDS_MAX (include/mprg.h)
-PREPARE_LDS_CLASSES = (12 * 1024, 24 * 1024, PREPARE_LDS_MAX)      # one launch per class of LDS need (bytes)
+PREPARE_LDS_MAX = 156 * 1024         # MPRG_KMEANS_PREPARE_LDS_MAX (include/mprg.h)
+PREPARE_LDS_CLASSES = (12 * 1024, 24 * 1024, 64 * 1024, PREPARE_LDS_MAX)      # one launch per class of LDS need (bytes)
 TILE_COLS = 1024
 IUPAC = {"R": "GA", "Y": "TC", "K": "GT", "M": "AC", "S": "GC", "W": "AT", "A": "A", "C": "C", "G": "G", "T": "T"}
 
