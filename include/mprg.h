@@ -164,7 +164,9 @@ int mprg_kmeans_restarts(const int64_t *prob, const int32_t *kinfo, int n_fits, 
                          const double *xcounts, double *ws, int32_t *km_status, void *stream);
 int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *xcounts,
                        double *ws, int32_t *labels, double *km_info, void *stream);
-/* A11, restarts + select as ONE launch of persistent workgroups (the throughput form): at most n_slots workgroups, each
+/* A11, restarts + select as ONE launch.  slot_ws == NULL (the form the batch host uses): one workgroup per fit, restart
+ * regions in the problems' workspaces exactly as for mprg_kmeans_restarts (kinfo field 2 honoured), next_fit unused.
+ * slot_ws != NULL: persistent workgroups: at most n_slots workgroups, each
  * taking the next unclaimed fit (next_fit: one int32 of device scratch, zeroed by the call; list the biggest fits first)
  * and keeping the per-restart arrays of its current fit in its own scratch slot
  * (slot_ws + b * slot_stride_doubles; slot_stride_doubles >= n_init * mprg_kmeans_workspace_doubles' per-restart part for

@@ -151,7 +151,8 @@ int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts,
         raised = true;
       }
     }
-    LAUNCH_LDS(k_kmeans_prepare_lds, n_lds, 256, lds_bytes, stream, lds_list, prob, xcounts, ws);
+    // LDS decides how many of these workgroups a CU holds: the big classes get the threads the small ones get from residency
+    LAUNCH_LDS(k_kmeans_prepare_lds, n_lds, lds_bytes > 24 * 1024 ? 1024 : 256, lds_bytes, stream, lds_list, prob, xcounts, ws);
   }
   return check_launch("k_kmeans_prepare");
 }
@@ -170,6 +171,12 @@ int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, int n_fits, int n
                     int32_t *next_fit, int32_t *labels, double *km_info, int32_t *km_status, void *stream) {
   if (n_fits <= 0) return 0;
   if (n_init > KM_RMAX) return fail("n_init must be <= 16");
+  static_assert(KM_SEL_LABELS * sizeof(int32_t) <= KM_XL_BYTES, "the selection's label staging lives in the restarts' LDS pool");
+  if (!slot_ws) {                      // no scratch slots: one workgroup per fit on the restart regions of the problems' workspaces
+    LAUNCH(k_kmeans_restart_select, n_fits, env_threads("MPRG_KM_THREADS", 256), stream, prob, kinfo, n_init, uniforms_dev, xcounts,
+           ws, labels, km_info, km_status);
+    return check_launch("k_kmeans_restart_select");
+  }
   if (n_slots <= 0 || slot_stride_doubles <= 0) return fail("mprg_kmeans_fit: no scratch slots");
   if (hipMemsetAsync(next_fit, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return fail("memset");
   const int grid = n_fits < n_slots ? n_fits : n_slots;

@@ -23,13 +23,11 @@ from .msa import CODE_GAP, decode
 
 KIND_LEAF, KIND_INTERVAL, KIND_CLUSTER = 0, 1, 2
 FUSED_VIEWS = os.environ.get("MPRG_FUSED_VIEWS", "1") != "0"     # fused small-view launch shape of mprg_partition
-# KMeans rounds: mprg_kmeans_restarts + mprg_kmeans_select with one restart region per problem (default), or — with
-# MPRG_KMEANS_SLOTS=1 — mprg_kmeans_fit: persistent workgroups that claim fits and keep the per-restart arrays in their own
-# scratch slot, selection fused.  Measured on one MI355X, same box (profiles/r02/kmeans_forms.md): exclusive pass 47.7 ms
-# (two launches) against 53.6 ms (persistent) per 3 000 alignments; ten workers 36.3 k against 37.3 k MSAs/s (within the
-# run-to-run noise); HBM-side traffic 2.3x against 3.0x the algorithmic bytes.  The persistent form needs 0.5 GB of scratch
-# instead of ~3 GB of restart regions per level and worker.  One launch per round as long as a full set of resident
-# workgroups (4 per CU) with slots of the round's largest need stays inside SLOT_BUDGET_DOUBLES (2 GiB); fits beyond
+# KMeans rounds: mprg_kmeans_fit with one restart region per problem and one workgroup per fit (restarts + selection in one
+# launch; default), or — with MPRG_KMEANS_SLOTS=1 — its persistent form: workgroups that claim fits and keep the per-restart
+# arrays in their own scratch slot (0.5 GB of scratch instead of ~3 GB of restart regions per level and worker; measured
+# slower on one MI355X: profiles/r02/kmeans_forms.md).  Persistent form: one launch per round as long as a full set of
+# resident workgroups (4 per CU) with slots of the round's largest need stays inside SLOT_BUDGET_DOUBLES (2 GiB); fits beyond
 # SLOT_SMALL_DOUBLES (2 MiB per slot: config D, Ddeep) get a launch of their own with as many slots as the budget holds.
 KMEANS_SLOTS = os.environ.get("MPRG_KMEANS_SLOTS", "0") != "0"
 SLOT_SMALL_DOUBLES = 1 << 18
@@ -397,10 +395,10 @@ class ForestEngine(BatchEngine):
 
     # ------------------------------------------------------------------------------------------------ KMeans rounds
     def _kmeans_round(self, active, k, D, V, uoff, d_ptab, d_uni, d_x, d_ws, d_labels):
-        """One k of the reference's loop (cluster_sequences.py:262-266) for the problems `active`.  Default form:
-        mprg_kmeans_restarts (one workgroup per fit and restart) + mprg_kmeans_select.  With MPRG_KMEANS_SLOTS=1:
-        mprg_kmeans_fit (persistent workgroups, scratch slots, selection fused) — one launch for the fits whose
-        per-restart arrays fit a small slot (~1 000 resident workgroups), one with fewer, bigger slots for the rest.
+        """One k of the reference's loop (cluster_sequences.py:262-266) for the problems `active`: mprg_kmeans_fit, one
+        workgroup per fit (its restarts side by side, then the selection).  With MPRG_KMEANS_SLOTS=1 the persistent form
+        of the same entry point — one launch for the fits whose per-restart arrays fit a small slot (~1 000 resident
+        workgroups), one with fewer, bigger slots for the rest.
         Returns (active reordered by launch, status, km_info rows)."""
         be = self.be
         small = self._rdoubles[active] <= SLOT_SMALL_DOUBLES
@@ -417,13 +415,11 @@ class ForestEngine(BatchEngine):
             if be.profile is not None and be.profile.get(name):
                 timed.append((name, len(be.profile[name]) - 1, rows))
 
-        if not KMEANS_SLOTS:
-            be.call("mprg_kmeans_restarts", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_uni), be.ptr(d_x), be.ptr(d_ws), be.ptr(d_st),
-                    be.stream)
-            mark("mprg_kmeans_restarts", slice(0, nA))
-            be.call("mprg_kmeans_select", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_labels),
-                    be.ptr(d_info), be.stream)
-            self.counters["launches"] += 2
+        if not KMEANS_SLOTS:             # restarts + selection of every fit of the round in one launch, one workgroup per fit
+            be.call("mprg_kmeans_fit", be.ptr(d_ptab), be.ptr(d_ki), nA, N_INIT, be.ptr(d_uni), be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, 0,
+                    be.ptr(d_labels), be.ptr(d_info), be.ptr(d_st), be.stream)
+            mark("mprg_kmeans_fit", slice(0, nA))
+            self.counters["launches"] += 1
         for lo, hi in (((0, n_small), (n_small, nA)) if KMEANS_SLOTS else ()):
             n = hi - lo
             if not n:

@@ -7,6 +7,7 @@ PF = 12
 def run_kmeans_fits(be, fits, n_init=10, path="global", n_slots=3):
     """path: "global" = mprg_kmeans_restarts + mprg_kmeans_select ("global-nocounts": without the count matrices, i.e. every
     fit reads the centred matrix from its workspace) (one restart region per problem, two launches);
+    "one-launch" = mprg_kmeans_fit without scratch slots (a workgroup per fit: restarts, then selection);
     "fit" = mprg_kmeans_fit (persistent workgroups, per-restart arrays in `n_slots` scratch slots, selection fused)."""
     groups = {}
     for idx, f in enumerate(fits):
@@ -46,6 +47,9 @@ def run_kmeans_fits(be, fits, n_init=10, path="global", n_slots=3):
             d_slots = be.empty(8 * stride * n_slots)
             be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws),
                     be.ptr(d_slots), stride, n_slots, be.ptr(be.empty(16)), be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
+        elif path == "one-launch":
+            be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, 0,
+                    be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
         else:
             be.call("mprg_kmeans_restarts", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_u), 0 if path == "global-nocounts" else be.ptr(d_x),
                     be.ptr(d_ws), be.ptr(d_st1), be.stream)

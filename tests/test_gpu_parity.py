@@ -47,8 +47,8 @@ def test_kmeans_known_answers_persistent_workgroups(hip, golden_kmeans):
     selection fused), with a few slots (many fits per workgroup) and with as many slots as fits."""
     from tests.kmeans_direct import run_kmeans_fits
     fits = golden_kmeans["fits"]
-    for slots in (5, 4096):
-        got = run_kmeans_fits(hip, fits, path="fit", n_slots=slots)
+    for path, slots in (("one-launch", 0), ("fit", 5), ("fit", 4096)):      # one-launch: no scratch slots, a workgroup per fit
+        got = run_kmeans_fits(hip, fits, path=path, n_slots=slots)
         for g, f in zip(got, fits):
             assert g["labels"] == f["labels"]
             assert g["inertia_hex"] == f["inertia"]
@@ -82,6 +82,7 @@ def test_empty_cluster_relocation_on_gpu(hip):
     from tests.test_kmeans_relocation import check, degenerate_fits
     fits = degenerate_fits(8, 80)
     check(hip, fits)
+    check(hip, fits, path="one-launch")
     check(hip, fits, path="fit", n_slots=3)
     check(hip, fits, path="fit", n_slots=1024)
 
