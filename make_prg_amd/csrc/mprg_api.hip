@@ -83,7 +83,7 @@ int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *ro
     LAUNCH(k_partition, n_other, BLOCK_VIEW, stream, other_list, arena, views, rowidx, mask, min_match_length, maxrun, stack,
            ivflag, iv, n_iv, status, view_out);
   if (n_fused > 0)
-    LAUNCH(k_partition_fused, n_fused, BLOCK_VIEW, stream, fused_list, arena, views, rowidx, min_match_length, iv, n_iv, status,
+    LAUNCH(k_partition_fused, n_fused, env_threads("MPRG_PF_THREADS", BLOCK_VIEW), stream, fused_list, arena, views, rowidx, min_match_length, iv, n_iv, status,
            view_out);
   if (view_out) {                                  // the packed list of all triples of the call
     if (!iv_packed || !iv_count) return fail("mprg_partition: view_out needs iv_packed and iv_count");
@@ -100,7 +100,7 @@ int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t 
                       int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, void *stream) {
   if (n_views <= 0) return 0;
   LAUNCH(k_ungap_hash, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, ucodes, hashes, ulen);
-  LAUNCH(k_ungap_dedupe, n_views, BLOCK_VIEW, stream, arena, views, rowidx, kmer_size, ucodes, hashes, ulen, rep_u, rep_g,
+  LAUNCH(k_ungap_dedupe, n_views, env_threads("MPRG_DD_THREADS", BLOCK_VIEW), stream, arena, views, rowidx, kmer_size, ucodes, hashes, ulen, rep_u, rep_g,
          d_of_row, s_of_row, reps_pos, reps_len, seqrow, occ_off, summary);
   return check_launch("k_ungap_dedupe");
 }
@@ -199,7 +199,7 @@ int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32
   if (n_probs <= 0) return 0;
   if (k < 1 || k > KM_KMAX) return fail("mprg_cluster_further: k out of range");
   if (hipMemsetAsync(out_further, 0, sizeof(int32_t) * n_probs, (hipStream_t)stream) != hipSuccess) return fail("memset");
-  LAUNCH(k_cluster_majority, n_work_cols, CF_TILE, stream, arena, views, rowidx, prob, work_cols, k, d_of_row, labels,
+  LAUNCH(k_cluster_majority, n_work_cols, CF_THREADS, stream, arena, views, rowidx, prob, work_cols, k, d_of_row, labels,
          assign, scratch);
   LAUNCH(k_cluster_hamming, n_work_rows, CF_TILE, stream, arena, views, rowidx, prob, work_rows, d_of_row, labels,
          (const int32_t *)scratch, out_further);

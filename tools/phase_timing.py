@@ -29,7 +29,8 @@ names = ["k-means++ pick", "k-means++ score + first centres", "centre-centre dis
          "k-means++ first centre (pick of round 1)", "first centres copied + counts staged in LDS"]
 for nm, v in zip(names, c):
     print(f"{100 * v / c[:16].sum():6.1f} %  {nm}   ({v / max(eng.counters['fits'], 1):.0f} cycles per fit)")
-pn = ["column flags", "serial scan", "pass A (N rows)", "pass B (row comparison)", "merge", "packed copy", "record + atomic"]
+pn = ["gap runs (small views) / column flags (big views)", "serial scan", "pass A (N rows)", "pass B (row comparison)", "merge", "packed copy",
+      "record", "small views: view + row indices", "small views: cells into LDS", "small views: masks + column flags"]
 for nm, v in zip(pn, c[16:]):
     print(f"{100 * v / max(c[16:].sum(), 1):6.1f} %  k_partition: {nm}   ({v / 1e6:.1f} Mcycles)")
 print("fits", eng.counters["fits"], "cycles/fit", c[:16].sum() / max(eng.counters["fits"], 1))
