@@ -22,6 +22,10 @@ def _load(seed):
     return load_alignment_text(synth_config_fasta("C", seed))
 
 
+from make_prg_amd.utils.misc import effective_cpus
+N_PROCS = effective_cpus()
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 200_000
@@ -29,10 +33,10 @@ if __name__ == "__main__":
     import oracle.from_msa_oracle as orc
     orc.build_kmeans_lib()
     t0 = time.time()
-    with mp.get_context("fork").Pool(os.cpu_count()) as pool:
+    with mp.get_context("fork").Pool(N_PROCS) as pool:
         want = pool.map(_one, seeds, chunksize=2)
         msas = pool.map(_load, seeds, chunksize=8)
-    print(f"oracle: {n} alignments in {time.time() - t0:.0f}s on {os.cpu_count()} processes", flush=True)
+    print(f"oracle: {n} alignments in {time.time() - t0:.0f}s on {N_PROCS} processes", flush=True)
     from make_prg_amd.backend import HipBackend
     from make_prg_amd.forest import ForestEngine
     eng = ForestEngine(HipBackend(0), 5, 7)

@@ -50,6 +50,10 @@ def medium_cases(seed, n):
     return out
 
 
+from make_prg_amd.utils.misc import effective_cpus
+N_PROCS = effective_cpus()
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
     from tests.random_msas import random_cases
@@ -59,7 +63,7 @@ if __name__ == "__main__":
     orc.build_kmeans_lib()
     sets = {c: random_cases(1000 + i, n) for i, c in enumerate(COMBOS)}
     t0 = time.time()
-    with mp.get_context("fork").Pool(os.cpu_count()) as pool:
+    with mp.get_context("fork").Pool(N_PROCS) as pool:
         want = {c: pool.map(_one, [(t, c[0], c[1]) for t in sets[c]], chunksize=16) for c in COMBOS}
     print(f"oracle: {n * len(COMBOS)} alignments in {time.time() - t0:.0f}s", flush=True)
     from make_prg_amd.backend import HipBackend
