@@ -1,5 +1,10 @@
 """GPU-box helper: share of k_kmeans_restart's workgroup time per phase (diagnostic build -DKM_PHASE_TIMING,
-make_prg_amd/_lib/libmprg_hip_timing.so: shader-clock cycles of thread 0 between barriers, summed over all fits)."""
+make_prg_amd/_lib/libmprg_hip_timing.so: shader-clock cycles of thread 0 between barriers, summed over all fits).
+Build it first (in the container: hipcc cross-compiles; the .so travels with gpurun):
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-function -DKM_PHASE_TIMING \
+        -Iinclude make_prg_amd/csrc/mprg_api.hip -o make_prg_amd/_lib/libmprg_hip_timing.so
+The timers perturb kernels that run many short workgroups (one atomic per workgroup and mark): trust them for the KMeans
+fit, not for the small-view partition."""
 import ctypes
 import os
 import sys
