@@ -186,11 +186,14 @@ void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
  * A row takes part if d_of_row >= 0; its cluster is labels[prob[LABEL_OFF] + d_of_row] (labels == NULL: a single
  * cluster).  Ties in the per-column majority go to the symbol seen first in the order in which the reference enumerates
  * the cluster's rows (distinct sequence, then row).  If `assign` is given the labels of these problems are also copied
- * there (the fit is the accepted one).  out_further[n_probs] = 1 if some cluster is not one-reference-like. */
+ * there (the fit is the accepted one).  out_further[n_probs] = 1 if some cluster is not one-reference-like.
+ * km_info (optional, the km_info of the KMeans round these labels come from, problem p = fit p): lets the call follow
+ * mprg_kmeans_fit without a host decision in between — a fit with fewer than k distinct labels is not accepted
+ * (cluster_sequences.py:267-273: its labels are not copied to `assign`; the host ignores its out_further). */
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
                          int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                          const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
-                         int32_t *scratch, int32_t *out_further, void *stream);
+                         int32_t *scratch, int32_t *out_further, const double *km_info, void *stream);
 
 /* A12/A14 — cluster_sequences.py:287-296 + recursion_tree.py:558-572: row lists of the children of MultiClusterNodes.
  * split_info: n_probs x 3 int64 {number of KMeans clusters, offset of the problem's n_rows entries in pool_out,

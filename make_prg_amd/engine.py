@@ -371,6 +371,13 @@ class BatchEngine:
         """mprg_cluster_further for the problems of act_tab (rows of the problem table); returns bool per problem.
         (A one-workgroup form with the view's cells in LDS was built and measured in round 2: 10.3 ms against 7.4 ms per
         3 000 alignments — its 58 KB of LDS halve the residency of a kernel that is bound by instruction issue — dropped.)"""
+        launch = self._cluster_further_plan(d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further)
+        launch(None)
+        return self.be.download(d_further, np.int32, len(act_tab)).astype(bool)
+
+    def _cluster_further_plan(self, d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further):
+        """Uploads the work lists of mprg_cluster_further now and returns launch(d_km_info): the caller can put a KMeans
+        launch between the two (an upload waits for the stream's earlier kernels) and fetch d_further when it pleases."""
         be = self.be
         nA = len(act_tab)
         views = act_tab[:, 0]
@@ -385,12 +392,15 @@ class BatchEngine:
 
         wc, wr = items(ncol_t), items(nrow_t)
         d_sp, d_wc, d_wr = be.upload(act_tab), be.upload(wc), be.upload(wr)
-        be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp), nA, k,
-                be.ptr(d_dor), be.ptr(d_labels) if k > 1 else None, be.ptr(d_assign) if (k > 1 and d_assign is not None) else None,
-                be.ptr(d_wc), len(wc), be.ptr(d_wr), len(wr), be.ptr(d_scratch), be.ptr(d_further), be.stream,
-                work=float((sub[views, 5] * sub[views, 7]).sum()))      # the members' cells, read once per evaluated k
-        self.counters["launches"] += 2
-        return be.download(d_further, np.int32, nA).astype(bool)
+        work = float((sub[views, 5] * sub[views, 7]).sum())               # the members' cells, read once per evaluated k
+
+        def launch(d_km_info):
+            be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp), nA, k,
+                    be.ptr(d_dor), be.ptr(d_labels) if k > 1 else None, be.ptr(d_assign) if (k > 1 and d_assign is not None) else None,
+                    be.ptr(d_wc), len(wc), be.ptr(d_wr), len(wr), be.ptr(d_scratch), be.ptr(d_further),
+                    be.ptr(d_km_info) if d_km_info is not None else None, be.stream, work=work)
+            self.counters["launches"] += 2
+        return launch
 
     def _kmeans_prepare(self, d_ptab, D, V, d_x, d_ws):
         """mprg_kmeans_prepare with the problems split by the LDS their matrix needs (include/mprg.h): every workgroup of a

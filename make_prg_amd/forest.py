@@ -347,7 +347,10 @@ class ForestEngine(BatchEngine):
             active = active[(num_clusters[active] <= MAX_CLUSTERS) & (num_clusters[active] != D[active])]
             if not len(active):
                 break
-            active, st, info = self._kmeans_round(active, k, D, V, int(uoff_arr[k]), d_ptab, d_uni, d_x, d_ws, d_labels)
+            # KMeans of the round and, right behind it on the stream, cluster_further on its labels (the device accepts a fit's
+            # labels only if they hold k distinct values): one wait for the device per round instead of two
+            active, st, info, fur = self._kmeans_round(active, k, D, V, int(uoff_arr[k]), d_ptab, d_uni, d_x, d_ws, d_labels,
+                                                       (d_sub, d_rowidx, sub, ptab, dd["d_of_row"], d_assign, d_scratch, d_further))
             nA = len(active)
             if (st & 2).any():
                 raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
@@ -357,10 +360,7 @@ class ForestEngine(BatchEngine):
             self.counters["kmeans_bytes"] += kb
             good = info[:, 3].astype(np.int64) >= k
             num_clusters[active[~good]] -= 1                     # cluster_sequences.py:267-273: revert and stop
-            active = active[good]
-            if len(active):                                      # also commits the accepted labels
-                active = active[self._cluster_further(d_sub, d_rowidx, sub, ptab[active], k, dd["d_of_row"], d_labels,
-                                                      d_assign, d_scratch, d_further)]
+            active = active[good & fur]
         # ---- MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
         splits = np.nonzero((num_clusters != 1) & (num_clusters != D))[0]
         if not len(splits):
@@ -394,12 +394,13 @@ class ForestEngine(BatchEngine):
         R["n_child"][pj] = nchild
 
     # ------------------------------------------------------------------------------------------------ KMeans rounds
-    def _kmeans_round(self, active, k, D, V, uoff, d_ptab, d_uni, d_x, d_ws, d_labels):
+    def _kmeans_round(self, active, k, D, V, uoff, d_ptab, d_uni, d_x, d_ws, d_labels, cf):
         """One k of the reference's loop (cluster_sequences.py:262-266) for the problems `active`: mprg_kmeans_fit, one
         workgroup per fit (its restarts side by side, then the selection).  With MPRG_KMEANS_SLOTS=1 the persistent form
         of the same entry point — one launch for the fits whose per-restart arrays fit a small slot (~1 000 resident
         workgroups), one with fewer, bigger slots for the rest.
-        Returns (active reordered by launch, status, km_info rows)."""
+        cluster_further on the round's labels follows on the stream.  Returns (active reordered by launch, status,
+        km_info rows, cluster_further answers)."""
         be = self.be
         small = self._rdoubles[active] <= SLOT_SMALL_DOUBLES
         # biggest first (the launch's tail is its largest fit); the persistent form lists its small-slot class first
@@ -409,6 +410,8 @@ class ForestEngine(BatchEngine):
         ki = np.empty((nA, 5), np.int32)
         ki[:, 0], ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = active, k, 0, uoff, 0
         d_ki, d_st, d_info, d_next = be.upload(ki), be.zeros(4 * nA), be.empty(64 * nA), be.empty(16)
+        d_sub, d_rowidx, sub, ptab, d_dor, d_assign, d_scratch, d_further = cf
+        launch_cf = self._cluster_further_plan(d_sub, d_rowidx, sub, ptab[active], k, d_dor, d_labels, d_assign, d_scratch, d_further)
         timed = []                                                      # (entry point, its event slot, rows) when profiling
 
         def mark(name, rows):
@@ -433,12 +436,14 @@ class ForestEngine(BatchEngine):
                     be.ptr(off(d_st, 4)), be.stream)
             self.counters["launches"] += 1
             mark("mprg_kmeans_fit", slice(lo, hi))
+        launch_cf(d_info)
         st = be.download(d_st, np.int32, nA)
         info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
+        fur = be.download(d_further, np.int32, nA).astype(bool)
         for name, ev, rows in timed:         # algorithmic bytes are known only after the fits: 8 D V (Elkan iterations + n_init)
             a0, a1, _ = be.profile[name][ev]
             be.profile[name][ev] = (a0, a1, float((8.0 * D[active[rows]] * V[active[rows]] * (info[rows, 4] + N_INIT)).sum()))
-        return active, st, info
+        return active, st, info, fur
 
     # ------------------------------------------------------------------------------------------------ tables
     def _finalize_tables(self):
