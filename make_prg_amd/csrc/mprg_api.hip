@@ -152,7 +152,8 @@ int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts,
       }
     }
     // LDS decides how many of these workgroups a CU holds: the big classes get the threads the small ones get from residency
-    LAUNCH_LDS(k_kmeans_prepare_lds, n_lds, lds_bytes > 24 * 1024 ? 1024 : 256, lds_bytes, stream, lds_list, prob, xcounts, ws);
+    const int prep_threads = env_threads("MPRG_KP_THREADS", lds_bytes > 64 * 1024 ? 1024 : (lds_bytes > 24 * 1024 ? 512 : 256));
+    LAUNCH_LDS(k_kmeans_prepare_lds, n_lds, prep_threads, lds_bytes, stream, lds_list, prob, xcounts, ws);
   }
   return check_launch("k_kmeans_prepare");
 }
