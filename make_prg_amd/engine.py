@@ -375,14 +375,12 @@ class BatchEngine:
         launch(None)
         return self.be.download(d_further, np.int32, len(act_tab)).astype(bool)
 
-    def _cluster_further_plan(self, d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further):
-        """Uploads the work lists of mprg_cluster_further now and returns launch(d_km_info): the caller can put a KMeans
-        launch between the two (an upload waits for the stream's earlier kernels) and fetch d_further when it pleases."""
-        be = self.be
+    @staticmethod
+    def _cluster_further_items(sub, act_tab):
+        """Work lists of mprg_cluster_further for the problems of act_tab: (problem, column tile), (problem, row chunk), and
+        the members' cells (the algorithmic bytes of one evaluated k)."""
         nA = len(act_tab)
         views = act_tab[:, 0]
-        ncol_t = (sub[views, 7] + 255) // 256
-        nrow_t = (sub[views, 5] + 255) // 256
 
         def items(cnt):
             w = np.empty((int(cnt.sum()), 2), np.int32)
@@ -390,14 +388,23 @@ class BatchEngine:
             w[:, 1] = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
             return w
 
-        wc, wr = items(ncol_t), items(nrow_t)
-        d_sp, d_wc, d_wr = be.upload(act_tab), be.upload(wc), be.upload(wr)
-        work = float((sub[views, 5] * sub[views, 7]).sum())               # the members' cells, read once per evaluated k
+        return items((sub[views, 7] + 255) // 256), items((sub[views, 5] + 255) // 256), float((sub[views, 5] * sub[views, 7]).sum())
+
+    def _cluster_further_plan(self, d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further, staged=None):
+        """Uploads the work lists of mprg_cluster_further now and returns launch(d_km_info): the caller can put a KMeans
+        launch between the two (an upload waits for the stream's earlier kernels) and fetch d_further when it pleases.
+        staged: (device act_tab, device column items, n, device row items, n, work) if the caller has uploaded them already."""
+        be = self.be
+        nA = len(act_tab)
+        if staged is None:
+            wc, wr, work = self._cluster_further_items(sub, act_tab)
+            staged = (be.upload(act_tab), be.upload(wc), len(wc), be.upload(wr), len(wr), work)
+        d_sp, d_wc, n_wc, d_wr, n_wr, work = staged
 
         def launch(d_km_info):
             be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp), nA, k,
                     be.ptr(d_dor), be.ptr(d_labels) if k > 1 else None, be.ptr(d_assign) if (k > 1 and d_assign is not None) else None,
-                    be.ptr(d_wc), len(wc), be.ptr(d_wr), len(wr), be.ptr(d_scratch), be.ptr(d_further),
+                    be.ptr(d_wc), n_wc, be.ptr(d_wr), n_wr, be.ptr(d_scratch), be.ptr(d_further),
                     be.ptr(d_km_info) if d_km_info is not None else None, be.stream, work=work)
             self.counters["launches"] += 2
         return launch

@@ -409,9 +409,28 @@ class ForestEngine(BatchEngine):
         nA, n_small = len(active), int(small.sum())
         ki = np.empty((nA, 5), np.int32)
         ki[:, 0], ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = active, k, 0, uoff, 0
-        d_ki, d_st, d_info, d_next = be.upload(ki), be.zeros(4 * nA), be.empty(64 * nA), be.empty(16)
-        d_sub, d_rowidx, sub, ptab, d_dor, d_assign, d_scratch, d_further = cf
-        launch_cf = self._cluster_further_plan(d_sub, d_rowidx, sub, ptab[active], k, d_dor, d_labels, d_assign, d_scratch, d_further)
+        d_sub, d_rowidx, sub, ptab, d_dor, d_assign, d_scratch, _ = cf
+        # everything the round's launches read goes up in ONE copy, everything the host reads comes back in ONE (a copy is
+        # a ~16 us launch of its own on the device and a wait on the host: seven per round were 3 % of the device time)
+        act_tab = ptab[active]
+        wc, wr, cf_work = self._cluster_further_items(sub, act_tab)
+        parts = [act_tab, ki, wc, wr]
+        offs, o = [], 0
+        for a in parts:
+            offs.append(o)
+            o += (a.nbytes + 15) & ~15
+        packed = np.zeros(max(o, 16), np.uint8)
+        for a, at in zip(parts, offs):
+            packed[at:at + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        d_in = be.upload(packed)
+        d_ki = _Offset(be, d_in, offs[1])
+        out_info, out_st, out_fur = 0, 64 * nA, 64 * nA + ((4 * nA + 15) & ~15)
+        d_out = be.zeros(out_fur + 4 * nA + 16)                       # km_info | km_status (zeroed: the kernels OR into it) | further
+        d_info, d_st, d_further = _Offset(be, d_out, out_info), _Offset(be, d_out, out_st), _Offset(be, d_out, out_fur)
+        d_next = be.empty(16)
+        launch_cf = self._cluster_further_plan(d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further,
+                                               staged=(_Offset(be, d_in, offs[0]), _Offset(be, d_in, offs[2]), len(wc),
+                                                       _Offset(be, d_in, offs[3]), len(wr), cf_work))
         timed = []                                                      # (entry point, its event slot, rows) when profiling
 
         def mark(name, rows):
@@ -437,9 +456,10 @@ class ForestEngine(BatchEngine):
             self.counters["launches"] += 1
             mark("mprg_kmeans_fit", slice(lo, hi))
         launch_cf(d_info)
-        st = be.download(d_st, np.int32, nA)
-        info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
-        fur = be.download(d_further, np.int32, nA).astype(bool)
+        raw = be.download(d_out, np.uint8, out_fur + 4 * nA)
+        info = raw[:64 * nA].view(np.float64).reshape(nA, 8)
+        st = raw[out_st:out_st + 4 * nA].view(np.int32).copy()
+        fur = raw[out_fur:out_fur + 4 * nA].view(np.int32).astype(bool)
         for name, ev, rows in timed:         # algorithmic bytes are known only after the fits: 8 D V (Elkan iterations + n_init)
             a0, a1, _ = be.profile[name][ev]
             be.profile[name][ev] = (a0, a1, float((8.0 * D[active[rows]] * V[active[rows]] * (info[rows, 4] + N_INIT)).sum()))
