@@ -107,11 +107,13 @@ int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *ro
  * seqrow = row positions of the distinct long sequences; occ_off (at row_off + view index, D+1 entries) = exclusive
  * prefix sums of their k-mer occurrence counts.
  * summary int64[8*n_views] = {distinct ungapped, distinct gapped, D (distinct long), T (k-mer occurrences),
- * total ungapped length of the distinct rows, distinct short, 0, 0}.  scratch: hashes uint64[2*total_rows]. */
+ * total ungapped length of the distinct rows, distinct short, 0, 0}.  scratch: hashes uint64[2*total_rows].  * gcodes (optional, same size and layout as ucodes): receives a dense copy of every view's GAPPED rows (row i of a view at
+ * aux0 + i * pitch, pitch = columns rounded up to 16); the gapped comparison of this call and mprg_cluster_further read it
+ * instead of the arena when given. */
 int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views, int kmer_size,
                       const int32_t *work_rows, int n_work_rows, uint8_t *ucodes, uint64_t *hashes, int32_t *ulen,
                       int32_t *rep_u, int32_t *rep_g, int32_t *d_of_row, int32_t *s_of_row, int32_t *reps_pos,
-                      int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, void *stream);
+                      int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, uint8_t *gcodes, void *stream);
 
 /* A9b — from_msa/cluster_sequences.py:26-38 (count_distinct_kmers): k-mer dictionary in first-appearance order.
  * One workgroup per clustering problem.  prob: n_probs x MPRG_PROB_FIELDS int64 (see enum).  seqrow int32[]:
@@ -189,11 +191,13 @@ void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
  * there (the fit is the accepted one).  out_further[n_probs] = 1 if some cluster is not one-reference-like.
  * km_info (optional, the km_info of the KMeans round these labels come from, problem p = fit p): lets the call follow
  * mprg_kmeans_fit without a host decision in between — a fit with fewer than k distinct labels is not accepted
- * (cluster_sequences.py:267-273: its labels are not copied to `assign`; the host ignores its out_further). */
+ * (cluster_sequences.py:267-273: its labels are not copied to `assign`; the host ignores its out_further).
+ * gcodes (optional): the dense gapped copies mprg_ungap_dedupe wrote for these views (same `views` table): the kernels then
+ * read a view as one contiguous block instead of a narrow slice of every alignment row. */
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
                          int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                          const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
-                         int32_t *scratch, int32_t *out_further, const double *km_info, void *stream);
+                         int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, void *stream);
 
 /* A12/A14 — cluster_sequences.py:287-296 + recursion_tree.py:558-572: row lists of the children of MultiClusterNodes.
  * split_info: n_probs x 3 int64 {number of KMeans clusters, offset of the problem's n_rows entries in pool_out,

@@ -26,7 +26,7 @@ SIGNATURES = {
     "mprg_column_masks": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p, c_void_p]),
     "mprg_partition": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 9 +
                        [c_void_p, c_int, c_void_p, c_int, c_void_p]),
-    "mprg_ungap_dedupe": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p, c_int] + [c_void_p] * 13),
+    "mprg_ungap_dedupe": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p, c_int] + [c_void_p] * 14),
     "mprg_kmer_dictionary": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8),
     "mprg_kmer_counts": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7),
     "mprg_kmeans_workspace_doubles": (c_int64, [c_int64, c_int64, c_int, c_int]),
@@ -34,7 +34,7 @@ SIGNATURES = {
     "mprg_kmeans_restarts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mprg_kmeans_fit": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int64, c_int] + [c_void_p] * 5),
     "mprg_kmeans_select": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 5),
-    "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int] + [c_void_p] * 4),
+    "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int] + [c_void_p] * 5),
     "mprg_split_children": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 7),
     "mprg_leaf_jobs": (c_int, [c_void_p, c_int64] + [c_void_p] * 6),
     "mprg_emit_alleles": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

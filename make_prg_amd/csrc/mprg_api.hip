@@ -97,10 +97,10 @@ int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *ro
 int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views, int kmer_size,
                       const int32_t *work_rows, int n_work_rows, uint8_t *ucodes, uint64_t *hashes, int32_t *ulen,
                       int32_t *rep_u, int32_t *rep_g, int32_t *d_of_row, int32_t *s_of_row, int32_t *reps_pos,
-                      int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, void *stream) {
+                      int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, uint8_t *gcodes, void *stream) {
   if (n_views <= 0) return 0;
-  LAUNCH(k_ungap_hash, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, ucodes, hashes, ulen);
-  LAUNCH(k_ungap_dedupe, n_views, env_threads("MPRG_DD_THREADS", BLOCK_VIEW), stream, arena, views, rowidx, kmer_size, ucodes, hashes, ulen, rep_u, rep_g,
+  LAUNCH(k_ungap_hash, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, ucodes, hashes, ulen, gcodes);
+  LAUNCH(k_ungap_dedupe, n_views, env_threads("MPRG_DD_THREADS", BLOCK_VIEW), stream, arena, views, rowidx, kmer_size, ucodes, (const uint8_t *)gcodes, hashes, ulen, rep_u, rep_g,
          d_of_row, s_of_row, reps_pos, reps_len, seqrow, occ_off, summary);
   return check_launch("k_ungap_dedupe");
 }
@@ -196,14 +196,14 @@ int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, in
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
                          int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                          const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
-                         int32_t *scratch, int32_t *out_further, const double *km_info, void *stream) {
+                         int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, void *stream) {
   if (n_probs <= 0) return 0;
   if (k < 1 || k > KM_KMAX) return fail("mprg_cluster_further: k out of range");
   if (hipMemsetAsync(out_further, 0, sizeof(int32_t) * n_probs, (hipStream_t)stream) != hipSuccess) return fail("memset");
   LAUNCH(k_cluster_majority, n_work_cols, CF_THREADS, stream, arena, views, rowidx, prob, work_cols, k, d_of_row, labels,
-         assign, km_info, scratch);
+         assign, km_info, scratch, gcodes);
   LAUNCH(k_cluster_hamming, n_work_rows, CF_TILE, stream, arena, views, rowidx, prob, work_rows, d_of_row, labels,
-         (const int32_t *)scratch, out_further);
+         (const int32_t *)scratch, out_further, gcodes);
   return check_launch("k_cluster_further");
 }
 

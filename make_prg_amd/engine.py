@@ -367,11 +367,12 @@ class BatchEngine:
         return next_frontier
 
 
-    def _cluster_further(self, d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further):
+    def _cluster_further(self, d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further, d_gcodes=None):
         """mprg_cluster_further for the problems of act_tab (rows of the problem table); returns bool per problem.
         (A one-workgroup form with the view's cells in LDS was built and measured in round 2: 10.3 ms against 7.4 ms per
         3 000 alignments — its 58 KB of LDS halve the residency of a kernel that is bound by instruction issue — dropped.)"""
-        launch = self._cluster_further_plan(d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further)
+        launch = self._cluster_further_plan(d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further,
+                                            d_gcodes=d_gcodes)
         launch(None)
         return self.be.download(d_further, np.int32, len(act_tab)).astype(bool)
 
@@ -390,7 +391,8 @@ class BatchEngine:
 
         return items((sub[views, 7] + 255) // 256), items((sub[views, 5] + 255) // 256), float((sub[views, 5] * sub[views, 7]).sum())
 
-    def _cluster_further_plan(self, d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further, staged=None):
+    def _cluster_further_plan(self, d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further, staged=None,
+                              d_gcodes=None):
         """Uploads the work lists of mprg_cluster_further now and returns launch(d_km_info): the caller can put a KMeans
         launch between the two (an upload waits for the stream's earlier kernels) and fetch d_further when it pleases.
         staged: (device act_tab, device column items, n, device row items, n, work) if the caller has uploaded them already."""
@@ -405,7 +407,8 @@ class BatchEngine:
             be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), be.ptr(d_sp), nA, k,
                     be.ptr(d_dor), be.ptr(d_labels) if k > 1 else None, be.ptr(d_assign) if (k > 1 and d_assign is not None) else None,
                     be.ptr(d_wc), n_wc, be.ptr(d_wr), n_wr, be.ptr(d_scratch), be.ptr(d_further),
-                    be.ptr(d_km_info) if d_km_info is not None else None, be.stream, work=work)
+                    be.ptr(d_km_info) if d_km_info is not None else None, be.ptr(d_gcodes) if d_gcodes is not None else None,
+                    be.stream, work=work)
             self.counters["launches"] += 2
         return launch
 
@@ -435,7 +438,7 @@ class BatchEngine:
         """mprg_ungap_dedupe over the views of `d_sub`; returns the device buffers by name."""
         be = self.be
         R = max(tot_rows, 1)
-        b = dict(ucodes=be.empty(tot_u), hash=be.empty(16 * R), ulen=be.empty(4 * R), rep_u=be.empty(4 * R),
+        b = dict(ucodes=be.empty(tot_u), gcodes=be.empty(tot_u), hash=be.empty(16 * R), ulen=be.empty(4 * R), rep_u=be.empty(4 * R),
                  rep_g=be.empty(4 * R), d_of_row=be.empty(4 * R), s_of_row=be.empty(4 * R), reps_pos=be.empty(4 * R),
                  reps_len=be.empty(4 * R), seqrow=be.empty(4 * R), occ_off=be.empty(8 * (R + n_views)),
                  summary=be.empty(64 * max(n_views, 1)))
@@ -444,7 +447,7 @@ class BatchEngine:
         be.call("mprg_ungap_dedupe", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), n_views, self.L,
                 be.ptr(d_wr), len(wr), be.ptr(b["ucodes"]), be.ptr(b["hash"]), be.ptr(b["ulen"]), be.ptr(b["rep_u"]), be.ptr(b["rep_g"]),
                 be.ptr(b["d_of_row"]), be.ptr(b["s_of_row"]), be.ptr(b["reps_pos"]), be.ptr(b["reps_len"]),
-                be.ptr(b["seqrow"]), be.ptr(b["occ_off"]), be.ptr(b["summary"]), be.stream, work=work)
+                be.ptr(b["seqrow"]), be.ptr(b["occ_off"]), be.ptr(b["summary"]), be.ptr(b["gcodes"]), be.stream, work=work)
         self.counters["launches"] += 2
         return b
 

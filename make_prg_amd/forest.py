@@ -297,7 +297,7 @@ class ForestEngine(BatchEngine):
             """cluster_further() of the listed problems on the labels the select step just wrote (k=1: one cluster);
             the same call commits those labels as the problems' accepted assignment."""
             return self._cluster_further(d_sub, d_rowidx, sub, act_tab, k, dd["d_of_row"], d_labels, d_assign, d_scratch,
-                                         d_further)
+                                         d_further, d_gcodes=dd["gcodes"])
 
         # cluster_sequences.py:256: `while cluster_further(...)` is evaluated before any KMeans; a view whose rows are
         # already one-reference-like never uses its k-mer matrix, so the featurisation is only done for the others
@@ -350,7 +350,7 @@ class ForestEngine(BatchEngine):
             # KMeans of the round and, right behind it on the stream, cluster_further on its labels (the device accepts a fit's
             # labels only if they hold k distinct values): one wait for the device per round instead of two
             active, st, info, fur = self._kmeans_round(active, k, D, V, int(uoff_arr[k]), d_ptab, d_uni, d_x, d_ws, d_labels,
-                                                       (d_sub, d_rowidx, sub, ptab, dd["d_of_row"], d_assign, d_scratch, d_further))
+                                                       (d_sub, d_rowidx, sub, ptab, dd["d_of_row"], d_assign, d_scratch, dd["gcodes"]))
             nA = len(active)
             if (st & 2).any():
                 raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
@@ -409,7 +409,7 @@ class ForestEngine(BatchEngine):
         nA, n_small = len(active), int(small.sum())
         ki = np.empty((nA, 5), np.int32)
         ki[:, 0], ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = active, k, 0, uoff, 0
-        d_sub, d_rowidx, sub, ptab, d_dor, d_assign, d_scratch, _ = cf
+        d_sub, d_rowidx, sub, ptab, d_dor, d_assign, d_scratch, d_gcodes = cf
         # everything the round's launches read goes up in ONE copy, everything the host reads comes back in ONE (a copy is
         # a ~16 us launch of its own on the device and a wait on the host: seven per round were 3 % of the device time)
         act_tab = ptab[active]
@@ -430,7 +430,7 @@ class ForestEngine(BatchEngine):
         d_next = be.empty(16)
         launch_cf = self._cluster_further_plan(d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further,
                                                staged=(_Offset(be, d_in, offs[0]), _Offset(be, d_in, offs[2]), len(wc),
-                                                       _Offset(be, d_in, offs[3]), len(wr), cf_work))
+                                                       _Offset(be, d_in, offs[3]), len(wr), cf_work), d_gcodes=d_gcodes)
         timed = []                                                      # (entry point, its event slot, rows) when profiling
 
         def mark(name, rows):
