@@ -193,11 +193,14 @@ void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
  * mprg_kmeans_fit without a host decision in between — a fit with fewer than k distinct labels is not accepted
  * (cluster_sequences.py:267-273: its labels are not copied to `assign`; the host ignores its out_further).
  * gcodes (optional): the dense gapped copies mprg_ungap_dedupe wrote for these views (same `views` table): the kernels then
- * read a view as one contiguous block instead of a narrow slice of every alignment row. */
+ * read a view as one contiguous block instead of a narrow slice of every alignment row.
+ * kinfo (optional, the fit descriptors of that round, problem p = fit p): a problem whose descriptor says k = 0 sat the round out
+ * (mprg_forest_kloop_advance) and is skipped here too.  In mprg_kmeans_fit (slot_ws == NULL) a fit with k = 0 returns at once. */
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
                          int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                          const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
-                         int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, void *stream);
+                         int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, const int32_t *kinfo,
+                         void *stream);
 
 /* A12/A14 — cluster_sequences.py:287-296 + recursion_tree.py:558-572: row lists of the children of MultiClusterNodes.
  * split_info: n_probs x 3 int64 {number of KMeans clusters, offset of the problem's n_rows entries in pool_out,
@@ -219,6 +222,97 @@ int mprg_leaf_jobs(const int64_t *leaves, int64_t n_leaves, const int32_t *rowid
  * its non-gap cells.  Offsets come from the host's prefix sums over the recursion tree (site markers are written by
  * the host). */
 int mprg_emit_alleles(const uint8_t *arena, const int64_t *jobs, int64_t n_jobs, uint8_t *out, void *stream);
+
+/* ---- the recursion forest on the device (NodeFactory.build's decisions and children,
+ * recursion_tree.py:401-471; the k = 2..10 loop's control, cluster_sequences.py:256-274; node ids and PRG layout,
+ * recursion_tree.py:48-55, :194-300, prg_builder.py:100-119).
+ * The node table, the view / problem / work-item tables of every launch and the clustering loop's state live in device
+ * memory; each step is "count per item -> exclusive prefix sums -> fill".  The host (which still drives the recursion and owns
+ * every buffer) reads one small header of totals per step to size the next buffers.
+ * node table: MPRG_NODE_FIELDS int64 per node; the nodes of a recursion level are one contiguous range, the children of a node
+ * are contiguous inside the next level's range.
+ * F (every entry point's first argument): a HOST array of MPRG_F_FIELDS int64 — device addresses and sizes, read at call time.
+ * MPRG_F_VALS: int64 [items][MPRG_FOREST_VALS_COLS] scratch of the step; MPRG_F_SCAN_TMP: int64 [items / 2048 + 2][same];
+ * MPRG_F_HDR: int64 [MPRG_FOREST_HDR] of device memory that receives the step's totals (column sums, see each step). */
+enum {
+  MPRG_N_MSA = 0, MPRG_N_PARENT = 1, MPRG_N_LEVEL = 2 /* nesting level */, MPRG_N_ROWS_OFF = 3 /* row pool offset, -1: all rows */,
+  MPRG_N_NROWS = 4, MPRG_N_COL0 = 5, MPRG_N_NCOLS = 6, MPRG_N_FLAGS = 7 /* MPRG_NF_* */, MPRG_N_KIND = 8, MPRG_N_FIRST_CHILD = 9,
+  MPRG_N_NCHILD = 10, MPRG_N_LVL = 11 /* recursion level (breadth-first) that classified the node */,
+  MPRG_N_REPS_OFF = 12 /* offset of its distinct rows in that level's reps_pos / reps_len, -1: one allele = its columns */,
+  MPRG_N_NSEQ = 13 /* distinct ungapped rows */, MPRG_N_ACHARS = 14 /* their total length */, MPRG_N_AUX = 15, MPRG_NODE_FIELDS = 16
+};
+enum { MPRG_KIND_LEAF = 0, MPRG_KIND_INTERVAL = 1, MPRG_KIND_CLUSTER = 2 };
+enum { MPRG_NF_PURE = 1 /* match interval of a view without N / ambiguity codes: a one-allele leaf, no kernel visits it */,
+       MPRG_NF_SPECIAL = 2 /* its columns hold N or ambiguity codes */, MPRG_NF_FORCED = 4 /* tree root: never a cluster node */,
+       MPRG_NF_CAND = 8, MPRG_NF_DLEAF = 16, MPRG_NF_PQ = 32 };
+enum { MPRG_ASM_SIZE = 0, MPRG_ASM_PRE = 1 /* node id */, MPRG_ASM_SITE = 2, MPRG_ASM_TOTAL = 3, MPRG_ASM_START = 4,
+       MPRG_ASM_NSEQ = 5, MPRG_ASM_ACHARS = 6, MPRG_ASM_JOB = 7, MPRG_ASM_FIELDS = 8 };
+enum { MPRG_FOREST_VALS_COLS = 16, MPRG_FOREST_HDR = 96 };
+enum {
+  /* batch */
+  MPRG_F_NODES = 0, MPRG_F_N_NODES = 1, MPRG_F_META = 2 /* int64 [alignments][6]: rm, cm, pitchC, pitchS, rows, columns */,
+  MPRG_F_N_MSAS = 3, MPRG_F_FAILED = 4 /* int32 [alignments] */, MPRG_F_ERR_FIRST = 5 /* uint64 [alignments], all ones */,
+  MPRG_F_POOL = 6 /* int32 row pool */, MPRG_F_POOL_USED = 7, MPRG_F_ARENA = 8, MPRG_F_MAX_NESTING = 9, MPRG_F_MIN_MATCH = 10,
+  MPRG_F_FUSED_ENABLED = 11, MPRG_F_N_INIT = 12, MPRG_F_VALS = 13, MPRG_F_SCAN_TMP = 14, MPRG_F_HDR = 15,
+  /* level */
+  MPRG_F_F0 = 16, MPRG_F_N = 17, MPRG_F_LVL = 18, MPRG_F_VIEWS = 19, MPRG_F_VIEW2NODE = 20, MPRG_F_FUSED_LIST = 21,
+  MPRG_F_OTHER_LIST = 22, MPRG_F_MASK_WORK = 23, MPRG_F_RPC_IDX = 24 /* rows per mask item = 1024 >> this */, MPRG_F_GAP_WORK = 25,
+  MPRG_F_VIEW_OUT = 26, MPRG_F_IV_PACKED = 27, MPRG_F_N_VIEWS = 28,
+  MPRG_F_SUB = 29, MPRG_F_SELNODE = 30, MPRG_F_DD_WORK = 31, MPRG_F_SUMMARY = 32, MPRG_F_NSEL = 33,
+  MPRG_F_T1 = 34, MPRG_F_WORK_COLS = 35, MPRG_F_WORK_ROWS = 36, MPRG_F_FURTHER = 37, MPRG_F_NPQ = 38,
+  MPRG_F_PTAB0 = 39, MPRG_F_PTAB = 40, MPRG_F_DV = 41, MPRG_F_P = 42, MPRG_F_CLS_LISTS = 43 /* int32 [5][P] */,
+  MPRG_F_NUM_CLUSTERS = 44, MPRG_F_ACTIVE = 45, MPRG_F_KINFO = 46, MPRG_F_KM_INFO = 47, MPRG_F_KM_STATUS = 48,
+  MPRG_F_SPT = 49, MPRG_F_SP = 50, MPRG_F_SPLITNODE = 51, MPRG_F_CHILD_SIZES = 52, MPRG_F_NSPLITS = 53,
+  /* assembly */
+  MPRG_F_ASM = 54, MPRG_F_ROOT_OF = 55, MPRG_F_SPECIAL_LIST = 56, MPRG_F_SPECIAL_CAP = 57, MPRG_F_PATCH = 58, MPRG_F_N_PATCH = 59,
+  MPRG_F_LEVELS = 60 /* HOST int64 [levels][4]: first node, nodes, reps_pos, reps_len (device addresses or 0) */, MPRG_F_N_LEVELS = 61,
+  MPRG_F_VALS_MSA = 62 /* int64 [alignments][cols]: col 0 becomes tree base, then text base */, MPRG_F_VALS_NODE = 63,
+  MPRG_F_VALS_POS = 64, MPRG_F_N_SITES = 65, MPRG_F_JOBS = 66, MPRG_F_OUT = 67, MPRG_F_MSA_BASE = 68, MPRG_F_UOFF = 69,
+  MPRG_F_FIELDS = 96
+};
+/* S1  frontier -> views.  hdr: 0 views, 1 their columns, 2 their rows, 3 fused views, 4 other views, 5-9 mask work items for
+ *     row chunks of 1024/512/256/128/64 rows, 10 gap-run row chunks, 11 cells, 12 cells of the other views.  The host picks MPRG_F_RPC_IDX from 5-9, allocates
+ *     and calls _fill: views, view2node, fused / other lists, work items of mprg_column_masks and mprg_partition. */
+int mprg_forest_frontier_count(const int64_t *F, void *stream);
+int mprg_forest_frontier_fill(const int64_t *F, void *stream);
+/* S2  after mprg_partition (view_out, iv_packed): status -> failed loci; leaf / multi-interval / clustering candidate.
+ *     hdr: 0 children of multi-interval nodes, 1 selected views (candidates + leaves with several distinct rows), 2 their rows,
+ *     3 bytes of their ungapped rows, 4 their columns, 5 row chunks of mprg_ungap_dedupe, 6 their cells.  _children: the child nodes
+ *     (at MPRG_F_N_NODES on), the selected views' table `sub`, selnode, the dedupe work items. */
+int mprg_forest_classify(const int64_t *F, void *stream);
+int mprg_forest_children(const int64_t *F, void *stream);
+/* S3  after mprg_ungap_dedupe (summary): leaf alleles of the selected views; candidates that go on (recursion_tree.py:538-556).
+ *     hdr: 0 problems of the k = 1 check, 1 their column tiles, 2 their row chunks, 3 cells of all candidates, 4 cells of the
+ *     problems. */
+int mprg_forest_cluster_count(const int64_t *F, void *stream);
+int mprg_forest_cluster_fill(const int64_t *F, void *stream);
+/* S4  after mprg_cluster_further(k = 1): hdr: 0 clustering problems, 1 bytes of k-mer tables, 2 bytes of first-appearance flags,
+ *     3 distinct long sequences.  _fill: MPRG_F_PTAB0 (fields 0-6, 10, 11). */
+int mprg_forest_problems_count(const int64_t *F, void *stream);
+int mprg_forest_problems_fill(const int64_t *F, void *stream);
+/* S5  after mprg_kmer_dictionary (MPRG_F_DV): hdr: 0 doubles of count matrices, 1 doubles of KMeans workspaces, 2-6 problems
+ *     per mprg_kmeans_prepare class (LDS need <= 12, 24, 64, 156 KB, global form), 7 / 8 work items of mprg_cluster_further
+ *     (column tiles, row chunks of ALL problems: MPRG_F_WORK_COLS / _ROWS are filled by _fill), 15 error: too many features, 16-20 largest
+ *     LDS need per class.  _fill: MPRG_F_PTAB in launch order (biggest fits first), class lists, loop state. */
+int mprg_forest_sizes_count(const int64_t *F, void *stream);
+int mprg_forest_sizes_fill(const int64_t *F, void *stream);
+/* S6  the clustering loop's control step before round k (k = 2 .. 11; cluster_sequences.py:256-274): settles round k-1 from
+ *     km_info / km_status / out_further, writes the kinfo of round k (k = 0: the problem is done, its workgroups return).
+ *     hdr (accumulated from mprg_forest_sizes_count on): 8 fits run, 9 KMeans algorithmic bytes (double), 10 unsupported fit,
+ *     12 cells visited by the rounds' mprg_cluster_further (double);
+ *     11 (reset per call) problems still active. */
+int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream);
+/* S7  after the loop: hdr: 0 new MultiClusterNodes, 1 their rows, 2 their children.  _fill: tables of mprg_split_children;
+ *     _split_children (after it): the nodes become cluster nodes, their children are appended at MPRG_F_N_NODES. */
+int mprg_forest_splits_count(const int64_t *F, void *stream);
+int mprg_forest_splits_fill(const int64_t *F, void *stream);
+int mprg_forest_split_children(const int64_t *F, void *stream);
+/* KA  PRG assembly.  _special: hdr 0 = leaves the host must expand (N / ambiguity codes), listed with their node rows.
+ *     _layout: node ids, site numbers, text lengths; hdr: 0 characters of all PRGs, 1 allele copy jobs.
+ *     _emit: text starts, jobs, every marker; follow with mprg_emit_alleles(jobs). */
+int mprg_forest_assemble_special(const int64_t *F, void *stream);
+int mprg_forest_assemble_layout(const int64_t *F, void *stream);
+int mprg_forest_assemble_emit(const int64_t *F, void *stream);
 
 /* (f)-1 output encoders, HOST functions (host pointers), one pass over a PRG string as PrgBuilder emits it.
  * reference make_prg/utils/prg_encoder.py:44-91 and make_prg/utils/gfa.py:16-109.

@@ -34,10 +34,27 @@ SIGNATURES = {
     "mprg_kmeans_restarts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mprg_kmeans_fit": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int64, c_int] + [c_void_p] * 5),
     "mprg_kmeans_select": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 5),
-    "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int] + [c_void_p] * 5),
+    "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int] + [c_void_p] * 6),
     "mprg_split_children": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 7),
     "mprg_leaf_jobs": (c_int, [c_void_p, c_int64] + [c_void_p] * 6),
     "mprg_emit_alleles": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mprg_forest_frontier_count": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_frontier_fill": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_classify": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_children": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_cluster_count": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_cluster_fill": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_problems_count": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_problems_fill": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_sizes_count": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_sizes_fill": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_splits_count": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_splits_fill": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_split_children": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_assemble_special": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_assemble_layout": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_assemble_emit": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_kloop_advance": (c_int, [c_void_p, c_int, c_void_p]),
     "mprg_random_sample_host": (None, [c_uint32, c_int, c_void_p]),
     "mprg_prg_encode_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p]),
     "mprg_fasta_scan_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),

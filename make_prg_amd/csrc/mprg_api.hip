@@ -13,6 +13,7 @@
 #include "k_kmeans.inc"
 #include "k_cluster.inc"
 #include "k_emit.inc"
+#include "k_forest.inc"
 #include "host_encoders.inc"
 
 static thread_local char g_err[512] = "";
@@ -196,14 +197,15 @@ int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, in
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
                          int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                          const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
-                         int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, void *stream) {
+                         int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, const int32_t *kinfo,
+                         void *stream) {
   if (n_probs <= 0) return 0;
   if (k < 1 || k > KM_KMAX) return fail("mprg_cluster_further: k out of range");
   if (hipMemsetAsync(out_further, 0, sizeof(int32_t) * n_probs, (hipStream_t)stream) != hipSuccess) return fail("memset");
   LAUNCH(k_cluster_majority, n_work_cols, CF_THREADS, stream, arena, views, rowidx, prob, work_cols, k, d_of_row, labels,
-         assign, km_info, scratch, gcodes);
+         assign, km_info, scratch, gcodes, kinfo);
   LAUNCH(k_cluster_hamming, n_work_rows, CF_TILE, stream, arena, views, rowidx, prob, work_rows, d_of_row, labels,
-         (const int32_t *)scratch, out_further, gcodes);
+         (const int32_t *)scratch, out_further, gcodes, kinfo);
   return check_launch("k_cluster_further");
 }
 
@@ -228,6 +230,173 @@ int mprg_emit_alleles(const uint8_t *arena, const int64_t *jobs, int64_t n_jobs,
   LAUNCH(k_emit_alleles, (n_jobs + 3) / 4, EMIT_THREADS, stream, arena, jobs, (long long)n_jobs, out);      // a wavefront per job
   return check_launch("k_emit_alleles");
 }
+
+// ---- the recursion forest on the device (k_forest.inc); F: host array of MPRG_F_FIELDS int64 ------------------------------
+#define FP(T, f) ((T *)(uintptr_t)F[f])
+#define FHDR FP(int64_t, MPRG_F_HDR)
+static int kf_count_done(const int64_t *F, long long n, int m, void *stream, const char *name) {
+  if (kf_scan(FP(int64_t, MPRG_F_VALS), n, m, FHDR, FP(int64_t, MPRG_F_SCAN_TMP), stream) != 0) return fail("scan");
+  return check_launch(name);
+}
+int mprg_forest_frontier_count(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_N];
+  if (n > 0) LAUNCH(k_fr_count, KF_GRID(n), 256, stream, FP(const int64_t, MPRG_F_NODES), (long long)F[MPRG_F_F0], n, (int)F[MPRG_F_MIN_MATCH],
+                    (int)F[MPRG_F_FUSED_ENABLED], FP(int64_t, MPRG_F_VALS));
+  return kf_count_done(F, n, 13, stream, "k_fr_count");
+}
+int mprg_forest_frontier_fill(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_N];
+  if (n <= 0) return 0;
+  LAUNCH(k_fr_fill, KF_GRID(n), 256, stream, FP(int64_t, MPRG_F_NODES), (long long)F[MPRG_F_F0], n, (int)F[MPRG_F_MIN_MATCH],
+         (int)F[MPRG_F_FUSED_ENABLED], FP(const int64_t, MPRG_F_VALS), FP(const int64_t, MPRG_F_META), (int)F[MPRG_F_RPC_IDX],
+         FP(int64_t, MPRG_F_VIEWS), FP(int64_t, MPRG_F_VIEW2NODE), FP(int32_t, MPRG_F_FUSED_LIST), FP(int32_t, MPRG_F_OTHER_LIST),
+         FP(int32_t, MPRG_F_MASK_WORK), FP(int32_t, MPRG_F_GAP_WORK));
+  return check_launch("k_fr_fill");
+}
+int mprg_forest_classify(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_N], nv = F[MPRG_F_N_VIEWS];
+  if (nv > 0) LAUNCH(k_lv_status, KF_GRID(nv), 256, stream, FP(const int64_t, MPRG_F_NODES), (long long)F[MPRG_F_F0], nv,
+                     FP(const int64_t, MPRG_F_VIEW2NODE), FP(const int32_t, MPRG_F_VIEW_OUT), FP(int32_t, MPRG_F_FAILED),
+                     FP(int64_t, MPRG_F_ERR_FIRST));
+  if (n > 0) LAUNCH(k_lv_classify, KF_GRID(n), 256, stream, FP(int64_t, MPRG_F_NODES), (long long)F[MPRG_F_F0], n, (int)F[MPRG_F_LVL],
+                    FP(const int32_t, MPRG_F_VIEW_OUT), FP(const int32_t, MPRG_F_FAILED), FP(int64_t, MPRG_F_VALS));
+  return kf_count_done(F, n, 7, stream, "k_lv_classify");
+}
+int mprg_forest_children(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_N];
+  if (n <= 0) return 0;
+  LAUNCH(k_lv_children, (n + 3) / 4, 256, stream, FP(int64_t, MPRG_F_NODES), (long long)F[MPRG_F_F0], n, (long long)F[MPRG_F_N_NODES],
+         FP(const int64_t, MPRG_F_VALS), FP(const int32_t, MPRG_F_VIEW_OUT), FP(const int32_t, MPRG_F_IV_PACKED));
+  if (F[MPRG_F_NSEL] > 0)
+    LAUNCH(k_lv_sub, KF_GRID(n), 256, stream, FP(const int64_t, MPRG_F_NODES), (long long)F[MPRG_F_F0], n, FP(const int64_t, MPRG_F_VALS),
+           FP(const int64_t, MPRG_F_VIEWS), FP(int64_t, MPRG_F_SUB), FP(int64_t, MPRG_F_SELNODE), FP(int32_t, MPRG_F_DD_WORK));
+  return check_launch("k_lv_children");
+}
+int mprg_forest_cluster_count(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_NSEL];
+  if (n > 0) LAUNCH(k_cl_classify, KF_GRID(n), 256, stream, FP(int64_t, MPRG_F_NODES), n, FP(const int64_t, MPRG_F_SELNODE),
+                    FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_SUMMARY), (int)F[MPRG_F_MAX_NESTING], FP(int64_t, MPRG_F_VALS));
+  return kf_count_done(F, n, 5, stream, "k_cl_classify");
+}
+int mprg_forest_cluster_fill(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_NSEL];
+  if (n <= 0 || F[MPRG_F_NPQ] <= 0) return 0;
+  LAUNCH(k_cl_fill_pq, KF_GRID(n), 256, stream, FP(const int64_t, MPRG_F_NODES), n, FP(const int64_t, MPRG_F_SELNODE),
+         FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_SUMMARY), FP(const int64_t, MPRG_F_VALS), FP(int64_t, MPRG_F_T1),
+         FP(int32_t, MPRG_F_WORK_COLS), FP(int32_t, MPRG_F_WORK_ROWS));
+  return check_launch("k_cl_fill_pq");
+}
+int mprg_forest_problems_count(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_NPQ];
+  if (n > 0) LAUNCH(k_pr_count, KF_GRID(n), 256, stream, n, FP(const int64_t, MPRG_F_T1), FP(const int32_t, MPRG_F_FURTHER),
+                    FP(const int64_t, MPRG_F_SUMMARY), FP(int64_t, MPRG_F_VALS));
+  return kf_count_done(F, n, 4, stream, "k_pr_count");
+}
+int mprg_forest_problems_fill(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_NPQ];
+  if (n <= 0 || F[MPRG_F_P] <= 0) return 0;
+  LAUNCH(k_pr_fill, KF_GRID(n), 256, stream, n, FP(const int64_t, MPRG_F_T1), FP(const int32_t, MPRG_F_FURTHER),
+         FP(const int64_t, MPRG_F_SUMMARY), FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_VALS), FP(int64_t, MPRG_F_PTAB0));
+  return check_launch("k_pr_fill");
+}
+int mprg_forest_sizes_count(const int64_t *F, void *stream) {
+  const long long P = F[MPRG_F_P];
+  if (hipMemsetAsync(FHDR, 0, sizeof(int64_t) * MPRG_FOREST_HDR, (hipStream_t)stream) != hipSuccess) return fail("memset");
+  if (P > 0) LAUNCH(k_sz_count, KF_GRID(P), 256, stream, P, FP(const int64_t, MPRG_F_PTAB0), FP(const int32_t, MPRG_F_DV),
+                    FP(const int64_t, MPRG_F_SUB), (int)F[MPRG_F_N_INIT], FP(int64_t, MPRG_F_VALS), FHDR);
+  return kf_count_done(F, P, 9, stream, "k_sz_count");
+}
+int mprg_forest_sizes_fill(const int64_t *F, void *stream) {
+  const long long P = F[MPRG_F_P];
+  if (P <= 0) return 0;
+  LAUNCH(k_sz_fill, KF_GRID(P), 256, stream, P, FP(const int64_t, MPRG_F_PTAB0), FP(const int32_t, MPRG_F_DV), FP(const int64_t, MPRG_F_SUB),
+         FP(const int64_t, MPRG_F_VALS), FHDR, FP(int64_t, MPRG_F_PTAB), FP(int32_t, MPRG_F_CLS_LISTS), FP(int32_t, MPRG_F_NUM_CLUSTERS),
+         FP(int32_t, MPRG_F_ACTIVE), FP(int32_t, MPRG_F_WORK_COLS), FP(int32_t, MPRG_F_WORK_ROWS));
+  return check_launch("k_sz_fill");
+}
+int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream) {
+  const long long P = F[MPRG_F_P];
+  if (P <= 0) return 0;
+  if (k < 2 || k > KM_KMAX + 1) return fail("mprg_forest_kloop_advance: k out of range");
+  if (hipMemsetAsync(FHDR + 11, 0, sizeof(int64_t), (hipStream_t)stream) != hipSuccess) return fail("memset");
+  LAUNCH(k_kl_advance, KF_GRID(P), 256, stream, P, k, (int)F[MPRG_F_N_INIT], FP(const int64_t, MPRG_F_PTAB), FP(const int64_t, MPRG_F_SUB),
+         FP(int32_t, MPRG_F_NUM_CLUSTERS), FP(int32_t, MPRG_F_ACTIVE), FP(int32_t, MPRG_F_KINFO), FP(const double, MPRG_F_KM_INFO), FP(int32_t, MPRG_F_KM_STATUS),
+         FP(const int32_t, MPRG_F_FURTHER), (int)F[MPRG_F_UOFF + (k <= KM_KMAX ? k : 0)], FHDR);
+  return check_launch("k_kl_advance");
+}
+int mprg_forest_splits_count(const int64_t *F, void *stream) {
+  const long long P = F[MPRG_F_P];
+  if (P > 0) LAUNCH(k_sp_count, KF_GRID(P), 256, stream, P, FP(const int64_t, MPRG_F_PTAB), FP(const int32_t, MPRG_F_NUM_CLUSTERS),
+                    FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_SUMMARY), FP(int64_t, MPRG_F_VALS));
+  return kf_count_done(F, P, 3, stream, "k_sp_count");
+}
+int mprg_forest_splits_fill(const int64_t *F, void *stream) {
+  const long long P = F[MPRG_F_P];
+  if (P <= 0 || F[MPRG_F_NSPLITS] <= 0) return 0;
+  LAUNCH(k_sp_fill, KF_GRID(P), 256, stream, P, FP(const int64_t, MPRG_F_PTAB), FP(const int32_t, MPRG_F_NUM_CLUSTERS),
+         FP(const int64_t, MPRG_F_SELNODE), FP(const int64_t, MPRG_F_VALS), (long long)F[MPRG_F_POOL_USED], FP(int64_t, MPRG_F_SPT),
+         FP(int64_t, MPRG_F_SP), FP(int64_t, MPRG_F_SPLITNODE));
+  return check_launch("k_sp_fill");
+}
+int mprg_forest_split_children(const int64_t *F, void *stream) {
+  const long long ns = F[MPRG_F_NSPLITS];
+  if (ns <= 0) return 0;
+  LAUNCH(k_sp_children, (ns + 3) / 4, 256, stream, FP(int64_t, MPRG_F_NODES), ns, (long long)F[MPRG_F_N_NODES], FP(const int64_t, MPRG_F_SP),
+         FP(const int64_t, MPRG_F_SPLITNODE), FP(const int32_t, MPRG_F_CHILD_SIZES), FP(const int64_t, MPRG_F_SPT),
+         FP(const int64_t, MPRG_F_SUMMARY));
+  return check_launch("k_sp_children");
+}
+int mprg_forest_assemble_special(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_N_NODES];
+  if (hipMemsetAsync(FHDR, 0, sizeof(int64_t) * MPRG_FOREST_HDR, (hipStream_t)stream) != hipSuccess) return fail("memset");
+  if (n > 0) LAUNCH(k_as_special, KF_GRID(n), 256, stream, FP(const int64_t, MPRG_F_NODES), n, FP(const int32_t, MPRG_F_FAILED),
+                    FP(int64_t, MPRG_F_SPECIAL_LIST), (int64_t)F[MPRG_F_SPECIAL_CAP], FHDR);
+  return check_launch("k_as_special");
+}
+int mprg_forest_assemble_layout(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_N_NODES], M = F[MPRG_F_N_MSAS];
+  if (n <= 0) return 0;
+  const int64_t *nodes = FP(const int64_t, MPRG_F_NODES), *root_of = FP(const int64_t, MPRG_F_ROOT_OF);
+  const int32_t *failed = FP(const int32_t, MPRG_F_FAILED);
+  int64_t *A = FP(int64_t, MPRG_F_ASM), *vm = FP(int64_t, MPRG_F_VALS_MSA), *vn = FP(int64_t, MPRG_F_VALS_NODE), *vp = FP(int64_t, MPRG_F_VALS_POS);
+  int64_t *tmp = FP(int64_t, MPRG_F_SCAN_TMP), *mb = FP(int64_t, MPRG_F_MSA_BASE);
+  const int64_t *LV = (const int64_t *)(uintptr_t)F[MPRG_F_LEVELS];
+  const int nl = (int)F[MPRG_F_N_LEVELS];
+  LAUNCH(k_as_init, KF_GRID(n), 256, stream, nodes, n, failed, A);
+  if (F[MPRG_F_N_PATCH] > 0) LAUNCH(k_as_patch, KF_GRID(F[MPRG_F_N_PATCH]), 256, stream, (long long)F[MPRG_F_N_PATCH], FP(const int64_t, MPRG_F_PATCH), A);
+  for (int l = nl - 2; l >= 0; --l) if (LV[4 * l + 1] > 0) LAUNCH(k_as_up, KF_GRID(LV[4 * l + 1]), 256, stream, nodes, (long long)LV[4 * l], (long long)LV[4 * l + 1], A, (int)A_SIZE);
+  for (int l = 0; l + 1 < nl; ++l) if (LV[4 * l + 1] > 0) LAUNCH(k_as_pre, KF_GRID(LV[4 * l + 1]), 256, stream, nodes, (long long)LV[4 * l], (long long)LV[4 * l + 1], A);
+  LAUNCH(k_as_tree_sizes, KF_GRID(M), 256, stream, M, root_of, (const int64_t *)A, vm);
+  if (kf_scan(vm, M, 1, FHDR + 2, tmp, stream) != 0) return fail("scan");
+  if (hipMemsetAsync(FP(int64_t, MPRG_F_N_SITES), 0, sizeof(int64_t) * M, (hipStream_t)stream) != hipSuccess) return fail("memset");
+  LAUNCH(k_as_openers, KF_GRID(n), 256, stream, nodes, n, failed, (const int64_t *)A, (const int64_t *)vm, vp, FP(int64_t, MPRG_F_N_SITES));
+  if (kf_scan(vp, n, 1, FHDR + 3, tmp, stream) != 0) return fail("scan");
+  LAUNCH(k_as_sites, KF_GRID(n), 256, stream, nodes, n, failed, A, (const int64_t *)vm, (const int64_t *)vp);
+  for (int l = nl - 2; l >= 0; --l) if (LV[4 * l + 1] > 0) LAUNCH(k_as_up, KF_GRID(LV[4 * l + 1]), 256, stream, nodes, (long long)LV[4 * l], (long long)LV[4 * l + 1], A, (int)A_TOTAL);
+  LAUNCH(k_as_msa_len, KF_GRID(M), 256, stream, M, root_of, failed, (const int64_t *)A, mb);
+  if (kf_scan(mb, M, 1, FHDR, tmp, stream) != 0) return fail("scan");
+  LAUNCH(k_as_job_count, KF_GRID(n), 256, stream, n, (const int64_t *)A, vn);
+  if (kf_scan(vn, n, 1, FHDR + 1, tmp, stream) != 0) return fail("scan");
+  return check_launch("k_as_layout");
+}
+int mprg_forest_assemble_emit(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_N_NODES], M = F[MPRG_F_N_MSAS];
+  if (n <= 0) return 0;
+  const int64_t *nodes = FP(const int64_t, MPRG_F_NODES), *root_of = FP(const int64_t, MPRG_F_ROOT_OF);
+  const int32_t *failed = FP(const int32_t, MPRG_F_FAILED);
+  int64_t *A = FP(int64_t, MPRG_F_ASM);
+  const int64_t *LV = (const int64_t *)(uintptr_t)F[MPRG_F_LEVELS];
+  const int nl = (int)F[MPRG_F_N_LEVELS];
+  LAUNCH(k_as_root_start, KF_GRID(M), 256, stream, M, root_of, failed, A, FP(const int64_t, MPRG_F_MSA_BASE));
+  for (int l = 0; l + 1 < nl; ++l) if (LV[4 * l + 1] > 0) LAUNCH(k_as_start, KF_GRID(LV[4 * l + 1]), 256, stream, nodes, (long long)LV[4 * l], (long long)LV[4 * l + 1], A);
+  for (int l = 0; l < nl; ++l) if (LV[4 * l + 1] > 0)
+    LAUNCH(k_as_leaf_jobs, KF_GRID(LV[4 * l + 1]), 256, stream, nodes, (long long)LV[4 * l], (long long)LV[4 * l + 1], failed, (const int64_t *)A,
+           FP(const int64_t, MPRG_F_VALS_NODE), FP(const int64_t, MPRG_F_META), FP(const int32_t, MPRG_F_POOL),
+           (const int32_t *)(uintptr_t)LV[4 * l + 2], (const int32_t *)(uintptr_t)LV[4 * l + 3], FP(int64_t, MPRG_F_JOBS), FP(uint8_t, MPRG_F_OUT));
+  return check_launch("k_as_emit");
+}
+#undef FP
+#undef FHDR
 
 // numpy.random.RandomState(seed).random_sample(n): MT19937, init_genrand seeding, 53-bit doubles
 void mprg_random_sample_host(uint32_t seed, int n, double *out) {

@@ -92,7 +92,7 @@ class BatchEngine:
         self._uniform_cache: Dict[int, object] = {}
         self.timers: Dict[str, float] = {}
         self.counters: Dict[str, float] = dict(cells_all=0, cells_clustered=0, kmeans_bytes=0, fits=0, levels=0,
-                                               launches=0)
+                                               launches=0, syncs=0)
 
     # ------------------------------------------------------------------------------------------------ packing
     def _resolve_pending_n(self, msas: List[MSA]):
@@ -408,7 +408,7 @@ class BatchEngine:
                     be.ptr(d_dor), be.ptr(d_labels) if k > 1 else None, be.ptr(d_assign) if (k > 1 and d_assign is not None) else None,
                     be.ptr(d_wc), n_wc, be.ptr(d_wr), n_wr, be.ptr(d_scratch), be.ptr(d_further),
                     be.ptr(d_km_info) if d_km_info is not None else None, be.ptr(d_gcodes) if d_gcodes is not None else None,
-                    be.stream, work=work)
+                    None, be.stream, work=work)
             self.counters["launches"] += 2
         return launch
 
@@ -434,18 +434,21 @@ class BatchEngine:
             be.call("mprg_kmeans_prepare", be.ptr(d_ptab), len(idx), be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, be.ptr(d_idx), len(idx),
                     be.stream, work=work)
 
-    def _dedupe(self, d_sub, d_rowidx, n_views: int, tot_rows: int, tot_u: int, work: float = 0.0, sub=None):
-        """mprg_ungap_dedupe over the views of `d_sub`; returns the device buffers by name."""
+    def _dedupe(self, d_sub, d_rowidx, n_views: int, tot_rows: int, tot_u: int, work: float = 0.0, sub=None, wr=None):
+        """mprg_ungap_dedupe over the views of `d_sub`; returns the device buffers by name.  wr: (device list of {view, row
+        chunk} items, their number) if the caller built them on the device, else they are made here from the host table `sub`."""
         be = self.be
         R = max(tot_rows, 1)
         b = dict(ucodes=be.empty(tot_u), gcodes=be.empty(tot_u), hash=be.empty(16 * R), ulen=be.empty(4 * R), rep_u=be.empty(4 * R),
                  rep_g=be.empty(4 * R), d_of_row=be.empty(4 * R), s_of_row=be.empty(4 * R), reps_pos=be.empty(4 * R),
                  reps_len=be.empty(4 * R), seqrow=be.empty(4 * R), occ_off=be.empty(8 * (R + n_views)),
                  summary=be.empty(64 * max(n_views, 1)))
-        wr = self._row_chunk_work(sub)
-        d_wr = be.upload(wr)
+        if wr is None:
+            w = self._row_chunk_work(sub)
+            wr = (be.upload(w), len(w))
+        d_wr, n_wr = wr
         be.call("mprg_ungap_dedupe", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), n_views, self.L,
-                be.ptr(d_wr), len(wr), be.ptr(b["ucodes"]), be.ptr(b["hash"]), be.ptr(b["ulen"]), be.ptr(b["rep_u"]), be.ptr(b["rep_g"]),
+                be.ptr(d_wr), n_wr, be.ptr(b["ucodes"]), be.ptr(b["hash"]), be.ptr(b["ulen"]), be.ptr(b["rep_u"]), be.ptr(b["rep_g"]),
                 be.ptr(b["d_of_row"]), be.ptr(b["s_of_row"]), be.ptr(b["reps_pos"]), be.ptr(b["reps_len"]),
                 be.ptr(b["seqrow"]), be.ptr(b["occ_off"]), be.ptr(b["summary"]), be.ptr(b["gcodes"]), be.stream, work=work)
         self.counters["launches"] += 2

@@ -319,9 +319,8 @@ def materialise_forest(eng, mi: int, alignment: MSA, prg_builder, leaf_of: Optio
     pool = eng.pool_host() if eng.pool_used else np.zeros(0, np.int64)
 
     def make(ni: int, parent) -> RecursiveTreeNode:
-        rl = int(t["rowlist"][ni])
-        rows = None if rl < 0 else pool[eng.rl_off[rl]:eng.rl_off[rl] + eng.rl_len[rl]].copy()
-        stored = SubAlignment(alignment, None if rl < 0 else rows, int(t["col0"][ni]), int(t["ncols"][ni]))
+        rows = eng.node_rows(ni, pool)
+        stored = SubAlignment(alignment, None if rows is None else rows.copy(), int(t["col0"][ni]), int(t["ncols"][ni]))
         level, kind = int(t["level"][ni]), int(t["kind"][ni])
         if kind == KIND_LEAF:
             leaf = LeafNode(level, stored, parent, prg_builder)
