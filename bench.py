@@ -132,11 +132,19 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1):
 
         def one(i):
             with bes[i].on_stream():
-                engs[i].run_forest()                          # recursion forest: kernels + array-at-a-time host control
-                prgs = engs[i].assemble_prgs(as_bytes=True)   # PRG text (ASCII) of every locus of the sub-batch
-                bes[i].synchronize()
-            last[i] = prgs
-            return sum(p is not None for p in prgs), sum(len(p) for p in prgs if p)
+                engs[i].run_forest()                          # recursion forest: kernels; the host only sizes buffers
+                # PRG text (ASCII) of every locus of the sub-batch: laid out and written on the device, copied to a pinned
+                # host buffer on the copy stream; collected one step later, so the copy overlaps the next step's kernels
+                return engs[i].assemble_prgs(as_bytes=True, lazy=True)
+
+        def collect(fins):
+            n_ok = chars = 0
+            for i, fin in enumerate(fins):
+                prgs = fin()
+                last[i] = prgs
+                n_ok += sum(p is not None for p in prgs)
+                chars += sum(len(p) for p in prgs if p is not None)
+            return n_ok, chars
 
         def end_to_end():
             """FASTA text -> PRG, .bin and .gfa bytes, nothing resident beforehand (a fresh engine; stream 0)."""
@@ -153,7 +161,6 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1):
                 t2 = time.perf_counter()
                 eng.run_forest()
                 prgs = eng.assemble_prgs(as_bytes=True)
-                bes[0].synchronize()
             t3 = time.perf_counter()
             n_bytes = 0
             for p in prgs:
@@ -191,9 +198,16 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1):
             if cmd == "steps":
                 n_ok = chars = 0
                 t0 = time.perf_counter()
+                pending = None
                 for _ in range(arg):
-                    res = list(pool.map(one, range(n_streams)))
-                    n_ok, chars = sum(r[0] for r in res), sum(r[1] for r in res)
+                    fins = list(pool.map(one, range(n_streams)))
+                    if pending is not None:
+                        collect(pending)
+                    pending = fins
+                if pending is not None:
+                    n_ok, chars = collect(pending)            # every step's text is on the host when the worker answers
+                for b in bes:
+                    b.synchronize()
                 conn.send(("done", (n_ok, chars, time.perf_counter() - t0)))
             elif cmd == "reset":                              # arg: HIP-event timing of every entry point on / off
                 for b in bes:

@@ -298,9 +298,8 @@ int mprg_forest_sizes_count(const int64_t *F, void *stream);
 int mprg_forest_sizes_fill(const int64_t *F, void *stream);
 /* S6  the clustering loop's control step before round k (k = 2 .. 11; cluster_sequences.py:256-274): settles round k-1 from
  *     km_info / km_status / out_further, writes the kinfo of round k (k = 0: the problem is done, its workgroups return).
- *     hdr (accumulated from mprg_forest_sizes_count on): 8 fits run, 9 KMeans algorithmic bytes (double), 10 unsupported fit,
- *     12 cells visited by the rounds' mprg_cluster_further (double);
- *     11 (reset per call) problems still active. */
+ *     hdr (accumulated from mprg_forest_sizes_count on): 80 fits run, 81 KMeans algorithmic bytes (double), 82 unsupported fit,
+ *     84 cells visited by the rounds' mprg_cluster_further (double); 83 (reset per call) problems still active. */
 int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream);
 /* S7  after the loop: hdr: 0 new MultiClusterNodes, 1 their rows, 2 their children.  _fill: tables of mprg_split_children;
  *     _split_children (after it): the nodes become cluster nodes, their children are appended at MPRG_F_N_NODES. */

@@ -155,6 +155,29 @@ class HipBackend(_Base):
             return np.empty(0, dtype)
         return buf[:nbytes].cpu().numpy().view(dtype)
 
+    def download_async(self, buf, nbytes: int, slot: Optional[int] = None):
+        """Start copying buf[:nbytes] into a PINNED host buffer on the backend's copy stream, behind everything enqueued on the
+        compute stream so far; returns (uint8 array over the pinned buffer, wait()).  The array's contents are valid after
+        wait(); successive calls alternate between two pinned buffers (slot None), so the copy of one batch overlaps the kernels
+        of the next and a result stays valid until the second following call.  utils/io_utils.py:105-110 writes these bytes to files."""
+        torch = self.torch
+        nbytes = int(nbytes)
+        if not hasattr(self, "_pinned"):
+            self._pinned, self._copy_stream, self._next_slot = {}, torch.cuda.Stream(self.device), 0
+        if slot is None:
+            slot, self._next_slot = self._next_slot, self._next_slot ^ 1
+        host = self._pinned.get(slot)
+        if host is None or host.numel() < nbytes:
+            host = self._pinned[slot] = torch.empty(max(nbytes + (nbytes >> 3), 1 << 20), dtype=torch.uint8, pin_memory=True)
+        self._copy_stream.wait_stream(self.stream_obj)
+        with torch.cuda.stream(self._copy_stream):
+            if nbytes:
+                host[:nbytes].copy_(buf[:nbytes], non_blocking=True)
+            buf.record_stream(self._copy_stream)          # the caching allocator must not hand buf out before the copy ran
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        return host[:nbytes].numpy(), done.synchronize
+
     def ptr(self, buf) -> int:
         return buf.mprg_addr if hasattr(buf, "mprg_addr") else buf.data_ptr()
 

@@ -318,7 +318,7 @@ int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream) {
   const long long P = F[MPRG_F_P];
   if (P <= 0) return 0;
   if (k < 2 || k > KM_KMAX + 1) return fail("mprg_forest_kloop_advance: k out of range");
-  if (hipMemsetAsync(FHDR + 11, 0, sizeof(int64_t), (hipStream_t)stream) != hipSuccess) return fail("memset");
+  if (hipMemsetAsync(FHDR + 83, 0, sizeof(int64_t), (hipStream_t)stream) != hipSuccess) return fail("memset");
   LAUNCH(k_kl_advance, KF_GRID(P), 256, stream, P, k, (int)F[MPRG_F_N_INIT], FP(const int64_t, MPRG_F_PTAB), FP(const int64_t, MPRG_F_SUB),
          FP(int32_t, MPRG_F_NUM_CLUSTERS), FP(int32_t, MPRG_F_ACTIVE), FP(int32_t, MPRG_F_KINFO), FP(const double, MPRG_F_KM_INFO), FP(int32_t, MPRG_F_KM_STATUS),
          FP(const int32_t, MPRG_F_FURTHER), (int)F[MPRG_F_UOFF + (k <= KM_KMAX ? k : 0)], FHDR);

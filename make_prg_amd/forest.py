@@ -270,8 +270,8 @@ class ForestEngine(BatchEngine):
         #      the control step settles the previous round on the device; a retired problem's workgroups return at once
         km_events, cf_events = [], []
         for k in range(2, MAX_CLUSTERS + 2):
-            hk = self._step("kloop_advance", k, n_hdr=12 if k >= 4 else 0)
-            if k > MAX_CLUSTERS or (hk is not None and hk[11] == 0):
+            hk = self._step("kloop_advance", k, n_hdr=HDR if k >= 4 else 0)
+            if k > MAX_CLUSTERS or (hk is not None and hk[83] == 0):
                 break
             be.call("mprg_kmeans_fit", be.ptr(d_ptab), be.ptr(d_kinfo), P, N_INIT, be.ptr(self._d_uni), be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, 0,
                     be.ptr(d_labels), be.ptr(d_info), be.ptr(d_st), be.stream)
@@ -281,10 +281,10 @@ class ForestEngine(BatchEngine):
             self.counters["launches"] += 1
         # ---- S7: MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
         self._scratch(P)
-        h = self._step("splits_count", n_hdr=13)
+        h = self._step("splits_count", n_hdr=HDR)
         n_splits, rows_sp, n_child = (int(x) for x in h[:3])
-        fits, km_bytes, cf_cells = int(h[8]), float(h[9:10].view(np.float64)[0]), float(h[12:13].view(np.float64)[0])
-        if h[10]:
+        fits, km_bytes, cf_cells = int(h[80]), float(h[81:82].view(np.float64)[0]), float(h[84:85].view(np.float64)[0])
+        if h[82]:
             raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
                             "is not restated on the device; refusing to continue with a possibly different result")
         self.counters["fits"] += fits
@@ -379,8 +379,10 @@ def _special_leaf_alleles(self: "ForestEngine", rows: np.ndarray) -> Dict[int, L
     return out
 
 
-def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool = False):
-    """PRG string of every alignment of the batch (None for loci dropped by the curation policy).
+def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool = False, lazy: bool = False):
+    """PRG string of every alignment of the batch (None for loci dropped by the curation policy).  lazy: returns a function
+    that waits for the text's copy to the host and returns the list — the copy then overlaps whatever the caller enqueues next
+    (as_bytes views stay valid until the second following assemble_prgs of this engine's backend).
     Device (mprg_forest_assemble_*): preorder ranks and site numbers, text lengths bottom-up, text offsets top-down over the
     node table; every leaf's alleles (mprg_emit_alleles) and every marker.  Host: the rare leaves with ambiguity codes.
     reference: PrgBuilder.build_prg prg_builder.py:100-105; traversals recursion_tree.py:194-201, :222-239, :266-300."""
@@ -429,55 +431,64 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool =
         be.call("mprg_emit_alleles", be.ptr(self.d_arena), be.ptr(d_jobs), n_jobs, be.ptr(d_out), be.stream,
                 work=float(2 * total_chars))
         self.counters["launches"] += 1
-    buf = be.download(d_out, np.uint8, total_chars)
-    msa_base = be.download(d_mbase, np.int64, VC * M).reshape(M, VC)[:, 0]
-    msa_len = np.diff(np.concatenate([msa_base, [total_chars]]))
+    # the text goes to a pinned host buffer on the copy stream; the caller may collect it later (lazy=True) so that the
+    # copy of this batch overlaps the kernels of the next one
+    msa_base = be.download(d_mbase, np.int64, VC * M).reshape(M, VC)[:, 0]       # (before the big copy: a copy queued behind
+    msa_len = np.diff(np.concatenate([msa_base, [total_chars]]))                  # 2.5 GB on the DMA engine waits for it)
     self._asm = self._site_count = None
     self._d_asm, self._d_nsites = d_asm, d_nsites
-    # ---- host: the text of the host-expanded leaves -------------------------------------------------------------------------
-    host_index = []
-    if host_leaf:
-        if not buf.flags.writeable:
-            buf = buf.copy()
-        A = self.asm
-        msa = self.tab["msa"]
-        for lf, seqs in host_leaf.items():
-            if self.failed[msa[lf]]:
-                continue
-            pos, site = int(A[lf, A_START]), int(A[lf, A_SITE])
-            many = len(seqs) > 1
-            if many:
-                mtxt = f" {site} ".encode()
-                buf[pos:pos + len(mtxt)] = np.frombuffer(mtxt, np.uint8)
-                pos += len(mtxt)
-            for i, q in enumerate(seqs):
-                buf[pos:pos + len(q)] = np.frombuffer(q.encode(), np.uint8)
-                host_index.append((lf, pos - int(msa_base[msa[lf]]), pos - int(msa_base[msa[lf]]) + len(q)))
-                pos += len(q)
-                if many:
-                    mtxt = f" {site + 1 if i < len(seqs) - 1 else site} ".encode()
-                    buf[pos:pos + len(mtxt)] = np.frombuffer(mtxt, np.uint8)
-                    pos += len(mtxt)
-    out: List[Optional[str]] = [None] * M
-    if as_bytes:          # zero-copy views into the batch buffer (ASCII)
-        mv = memoryview(buf)
-        for i in np.nonzero(~self.failed)[0]:
-            out[i] = mv[msa_base[i]:msa_base[i] + msa_len[i]]
-    else:
-        whole = buf.tobytes()
-        for i in np.nonzero(~self.failed)[0]:
-            out[i] = whole[msa_base[i]:msa_base[i] + msa_len[i]].decode()
+    index_parts = None
     if want_index:      # prg_index: every allele of every leaf (recursion_tree.py:276-300)
         A, t = self.asm, self.tab
         jobs = be.download(d_jobs, np.int64, 4 * n_jobs).reshape(-1, 4)
         dl = np.nonzero((t["kind"] == KIND_LEAF) & ~self.failed[t["msa"]] & (A[:, A_JOB] >= 0) & (A[:, A_NSEQ] > 0))[0]
         jl = np.repeat(dl, A[dl, A_NSEQ])
         js = jobs[:, 2] - msa_base[t["msa"][jl]]
-        leaf = np.concatenate([jl, np.asarray([x[0] for x in host_index], np.int64)])
-        s0 = np.concatenate([js, np.asarray([x[1] for x in host_index], np.int64)])
-        s1 = np.concatenate([js + jobs[:, 3], np.asarray([x[2] for x in host_index], np.int64)])
-        self.prg_index_arrays = (leaf, s0, s1)
-    return out
+        index_parts = (jl, js, js + jobs[:, 3])
+    if host_leaf:
+        _ = self.asm, self.tab
+    buf, wait = be.download_async(d_out, total_chars)
+
+    # the text of the host-expanded leaves: placed now (this engine's tables may belong to the next batch by the time the
+    # caller collects the text), written into the buffer once the copy has landed
+    text_patches, host_index = [], []
+    if host_leaf:
+        A, msa = self.asm, self.tab["msa"]
+        for lf, seqs in host_leaf.items():
+            if self.failed[msa[lf]]:
+                continue
+            pos, site = int(A[lf, A_START]), int(A[lf, A_SITE])
+            base = int(msa_base[msa[lf]])
+            many = len(seqs) > 1
+            parts = [f" {site} "] if many else []
+            at = pos + (len(parts[0]) if many else 0)
+            for i, q in enumerate(seqs):
+                parts.append(q)
+                host_index.append((lf, at - base, at - base + len(q)))
+                at += len(q)
+                if many:
+                    parts.append(f" {site + 1 if i < len(seqs) - 1 else site} ")
+                    at += len(parts[-1])
+            text_patches.append((pos, "".join(parts).encode()))
+    if index_parts is not None:
+        jl, s0, s1 = index_parts
+        self.prg_index_arrays = (np.concatenate([jl, np.asarray([x[0] for x in host_index], np.int64)]),
+                                 np.concatenate([s0, np.asarray([x[1] for x in host_index], np.int64)]),
+                                 np.concatenate([s1, np.asarray([x[2] for x in host_index], np.int64)]))
+    spans = list(zip(msa_base.tolist(), msa_len.tolist(), self.failed.tolist()))
+
+    def finish():
+        """Wait for the copy; one bytes-like (or str) per alignment."""
+        wait()
+        for pos, txt in text_patches:
+            buf[pos:pos + len(txt)] = np.frombuffer(txt, np.uint8)
+        if as_bytes:          # zero-copy views into the batch buffer (ASCII); valid until the buffer's slot is reused
+            mv = memoryview(buf)
+            return [None if bad else mv[a:a + ln] for a, ln, bad in spans]
+        whole = buf.tobytes()
+        return [None if bad else whole[a:a + ln].decode() for a, ln, bad in spans]
+
+    return finish if lazy else finish()
 
 
 def _asm_host(self: ForestEngine) -> np.ndarray:

@@ -59,6 +59,9 @@ class EmuBackend(_Base):
         nbytes = int(count) * np.dtype(dtype).itemsize
         return buf[:nbytes].copy().view(dtype)
 
+    def download_async(self, buf, nbytes, slot=None):
+        return buf[:int(nbytes)].copy(), (lambda: None)
+
     def ptr(self, buf):
         return buf.mprg_addr if hasattr(buf, "mprg_addr") else buf.ctypes.data
 

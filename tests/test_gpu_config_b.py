@@ -89,7 +89,7 @@ def test_config_d_at_full_size_properties(oracle_results):
     alleles = [u for u in units if not u.isdigit()]
     assert all(int(u) >= 5 for u in units if u.isdigit())
     distinct = {r.replace(b"-", b"").decode() for r in rows}
-    if eng.T.n == 2:
+    if eng.n_nodes == 2:
         assert len(alleles) == len(distinct) and set(alleles) == distinct
     else:                                   # a deeper tree: every input row must still be spelt by a path... at least
         assert set("".join(alleles)) <= set("ACGT")      # the alphabet holds

@@ -1,0 +1,47 @@
+"""GPU-box helper: where one step of the device-resident forest spends its wall time (one process, one stream).
+    python tools/forest_profile.py [batch] [steps]
+Prints per step: wall of run_forest / assemble_prgs, time inside downloads (waits for the device + copies), number of
+waits, and — last step, HIP events on — the device time per entry point."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from bench import make_batch
+from make_prg_amd.backend import HipBackend
+from make_prg_amd.forest import ForestEngine
+
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+texts, msas = make_batch(list(range(batch)), 16)
+be = HipBackend(0)
+eng = ForestEngine(be, 5, 7)
+eng.load(msas)
+be.synchronize()
+dl = dict(t=0.0, n=0, bytes=0)
+orig = be.download
+def timed_download(buf, dtype, count):
+    t0 = time.perf_counter()
+    out = orig(buf, dtype, count)
+    dl["t"] += time.perf_counter() - t0; dl["n"] += 1; dl["bytes"] += out.nbytes
+    return out
+be.download = timed_download
+for s in range(steps):
+    last = s == steps - 1
+    be.profile = {} if last else None
+    for k in eng.counters:
+        if k != "arena_bytes": eng.counters[k] = 0
+    dl.update(t=0.0, n=0, bytes=0)
+    t0 = time.perf_counter()
+    eng.run_forest()
+    t1 = time.perf_counter(); d1 = dict(dl)
+    prgs = eng.assemble_prgs(as_bytes=True)
+    be.synchronize()
+    t2 = time.perf_counter()
+    print(f"step {s}: run_forest {1e3*(t1-t0):.1f} ms (downloads {1e3*d1['t']:.1f} ms in {d1['n']} waits), assemble {1e3*(t2-t1):.1f} ms "
+          f"(downloads {1e3*(dl['t']-d1['t']):.1f} ms, {(dl['bytes']-d1['bytes'])/1e6:.1f} MB), nodes {eng.n_nodes}, levels {len(eng.levels)}, "
+          f"calls {eng.counters['launches']}", flush=True)
+prof = be.profile_summary()
+tot = sum(v["ms"] for v in prof.values())
+print(f"device time in entry points: {tot:.2f} ms")
+for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+    gb = v["bytes"] / max(v["ms"], 1e-9) * 1e-6 if v["bytes"] else 0
+    print(f"  {name:34s} {v['ms']:9.3f} ms {v['calls']:5d} calls  {gb:8.1f} GB/s")
