@@ -267,7 +267,8 @@ enum {
   MPRG_F_ASM = 54, MPRG_F_ROOT_OF = 55, MPRG_F_SPECIAL_LIST = 56, MPRG_F_SPECIAL_CAP = 57, MPRG_F_PATCH = 58, MPRG_F_N_PATCH = 59,
   MPRG_F_LEVELS = 60 /* HOST int64 [levels][4]: first node, nodes, reps_pos, reps_len (device addresses or 0) */, MPRG_F_N_LEVELS = 61,
   MPRG_F_VALS_MSA = 62 /* int64 [alignments][cols]: col 0 becomes tree base, then text base */, MPRG_F_VALS_NODE = 63,
-  MPRG_F_VALS_POS = 64, MPRG_F_N_SITES = 65, MPRG_F_JOBS = 66, MPRG_F_OUT = 67, MPRG_F_MSA_BASE = 68, MPRG_F_UOFF = 69,
+  MPRG_F_VALS_POS = 64, MPRG_F_N_SITES = 65, MPRG_F_JOBS = 66, MPRG_F_OUT = 67, MPRG_F_MSA_BASE = 68, MPRG_F_UOFF = 69 /* .. 79: offset of k's uniforms, k = 2..10 */,
+  MPRG_F_HDR_HOST = 80 /* optional: host-visible (pinned) int64 [MPRG_FOREST_HDR]; every step that fills MPRG_F_HDR copies it there */,
   MPRG_F_FIELDS = 96
 };
 /* S1  frontier -> views.  hdr: 0 views, 1 their columns, 2 their rows, 3 fused views, 4 other views, 5-9 mask work items for

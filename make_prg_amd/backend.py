@@ -155,6 +155,13 @@ class HipBackend(_Base):
             return np.empty(0, dtype)
         return buf[:nbytes].cpu().numpy().view(dtype)
 
+    def host_visible(self, nbytes: int):
+        """(buffer whose ptr() kernels may write, uint8 array over the same memory): page-locked host memory — hipHostMalloc
+        memory is mapped into the device's address space — for results a few words long: the device stores them, the host waits
+        for the stream and reads; no copy is enqueued."""
+        t = self.torch.zeros(int(nbytes), dtype=self.torch.uint8, pin_memory=True)
+        return t, t.numpy()
+
     def download_async(self, buf, nbytes: int, slot: Optional[int] = None):
         """Start copying buf[:nbytes] into a PINNED host buffer on the backend's copy stream, behind everything enqueued on the
         compute stream so far; returns (uint8 array over the pinned buffer, wait()).  The array's contents are valid after
@@ -168,7 +175,11 @@ class HipBackend(_Base):
             slot, self._next_slot = self._next_slot, self._next_slot ^ 1
         host = self._pinned.get(slot)
         if host is None or host.numel() < nbytes:
-            host = self._pinned[slot] = torch.empty(max(nbytes + (nbytes >> 3), 1 << 20), dtype=torch.uint8, pin_memory=True)
+            # both buffers at once: page-locking GBs takes longer than a whole batch, better paid during warm-up
+            for q in (slot, slot ^ 1):
+                if self._pinned.get(q) is None or self._pinned[q].numel() < nbytes:
+                    self._pinned[q] = torch.empty(max(nbytes + (nbytes >> 3), 1 << 20), dtype=torch.uint8, pin_memory=True)
+            host = self._pinned[slot]
         self._copy_stream.wait_stream(self.stream_obj)
         with torch.cuda.stream(self._copy_stream):
             if nbytes:

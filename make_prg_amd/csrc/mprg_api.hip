@@ -234,9 +234,13 @@ int mprg_emit_alleles(const uint8_t *arena, const int64_t *jobs, int64_t n_jobs,
 // ---- the recursion forest on the device (k_forest.inc); F: host array of MPRG_F_FIELDS int64 ------------------------------
 #define FP(T, f) ((T *)(uintptr_t)F[f])
 #define FHDR FP(int64_t, MPRG_F_HDR)
+static int kf_publish(const int64_t *F, void *stream, const char *name) {
+  if (F[MPRG_F_HDR_HOST]) LAUNCH(k_hdr_publish, 1, 128, stream, (const int64_t *)FHDR, FP(int64_t, MPRG_F_HDR_HOST));
+  return check_launch(name);
+}
 static int kf_count_done(const int64_t *F, long long n, int m, void *stream, const char *name) {
   if (kf_scan(FP(int64_t, MPRG_F_VALS), n, m, FHDR, FP(int64_t, MPRG_F_SCAN_TMP), stream) != 0) return fail("scan");
-  return check_launch(name);
+  return kf_publish(F, stream, name);
 }
 int mprg_forest_frontier_count(const int64_t *F, void *stream) {
   const long long n = F[MPRG_F_N];
@@ -322,7 +326,7 @@ int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream) {
   LAUNCH(k_kl_advance, KF_GRID(P), 256, stream, P, k, (int)F[MPRG_F_N_INIT], FP(const int64_t, MPRG_F_PTAB), FP(const int64_t, MPRG_F_SUB),
          FP(int32_t, MPRG_F_NUM_CLUSTERS), FP(int32_t, MPRG_F_ACTIVE), FP(int32_t, MPRG_F_KINFO), FP(const double, MPRG_F_KM_INFO), FP(int32_t, MPRG_F_KM_STATUS),
          FP(const int32_t, MPRG_F_FURTHER), (int)F[MPRG_F_UOFF + (k <= KM_KMAX ? k : 0)], FHDR);
-  return check_launch("k_kl_advance");
+  return kf_publish(F, stream, "k_kl_advance");
 }
 int mprg_forest_splits_count(const int64_t *F, void *stream) {
   const long long P = F[MPRG_F_P];
@@ -351,7 +355,7 @@ int mprg_forest_assemble_special(const int64_t *F, void *stream) {
   if (hipMemsetAsync(FHDR, 0, sizeof(int64_t) * MPRG_FOREST_HDR, (hipStream_t)stream) != hipSuccess) return fail("memset");
   if (n > 0) LAUNCH(k_as_special, KF_GRID(n), 256, stream, FP(const int64_t, MPRG_F_NODES), n, FP(const int32_t, MPRG_F_FAILED),
                     FP(int64_t, MPRG_F_SPECIAL_LIST), (int64_t)F[MPRG_F_SPECIAL_CAP], FHDR);
-  return check_launch("k_as_special");
+  return kf_publish(F, stream, "k_as_special");
 }
 int mprg_forest_assemble_layout(const int64_t *F, void *stream) {
   const long long n = F[MPRG_F_N_NODES], M = F[MPRG_F_N_MSAS];
@@ -377,7 +381,7 @@ int mprg_forest_assemble_layout(const int64_t *F, void *stream) {
   if (kf_scan(mb, M, 1, FHDR, tmp, stream) != 0) return fail("scan");
   LAUNCH(k_as_job_count, KF_GRID(n), 256, stream, n, (const int64_t *)A, vn);
   if (kf_scan(vn, n, 1, FHDR + 1, tmp, stream) != 0) return fail("scan");
-  return check_launch("k_as_layout");
+  return kf_publish(F, stream, "k_as_layout");
 }
 int mprg_forest_assemble_emit(const int64_t *F, void *stream) {
   const long long n = F[MPRG_F_N_NODES], M = F[MPRG_F_N_MSAS];

@@ -40,6 +40,7 @@ _F_NAMES = ("NODES N_NODES META N_MSAS FAILED ERR_FIRST POOL POOL_USED ARENA MAX
             "KM_INFO KM_STATUS SPT SP SPLITNODE CHILD_SIZES NSPLITS ASM ROOT_OF SPECIAL_LIST SPECIAL_CAP PATCH N_PATCH LEVELS "
             "N_LEVELS VALS_MSA VALS_NODE VALS_POS N_SITES JOBS OUT MSA_BASE UOFF").split()
 FI = {name: i for i, name in enumerate(_F_NAMES)}
+FI["HDR_HOST"] = 80
 F_FIELDS = 96
 PREPARE_CLASSES = 4                      # LDS classes of mprg_kmeans_prepare (+ the global-memory form)
 
@@ -63,9 +64,10 @@ class ForestEngine(BatchEngine):
         """One mprg_forest_* entry point; returns the first n_hdr words of the step's header (a wait for the device)."""
         self.be.call("mprg_forest_" + name, self.F.ctypes.data, *extra, self.be.stream, work=work)
         self.counters["launches"] += 1
-        if n_hdr:
+        if n_hdr:          # the device has published the header to pinned host memory: wait for the stream, read
             self.counters["syncs"] = self.counters.get("syncs", 0) + 1
-            return self.be.download(self.d_hdr, np.int64, n_hdr)
+            self.be.synchronize()
+            return self._hdr_host[:n_hdr].copy()
         return None
 
     def _scratch(self, n_items: int):
@@ -123,6 +125,9 @@ class ForestEngine(BatchEngine):
         self.pool_cap, self.pool_used = 0, 0
         self.d_pool = be.empty(16)
         self.d_hdr = be.zeros(8 * HDR)
+        if not hasattr(self, "_hdr_buf"):
+            self._hdr_buf, raw = be.host_visible(8 * HDR)
+            self._hdr_host = raw.view(np.int64)
         self.d_failed = be.upload(self.failed.astype(np.int32)) if M else be.zeros(16)
         self.d_err = be.upload(np.full(max(M, 1), np.iinfo(np.uint64).max, np.uint64))
         self.d_meta = be.upload(meta) if M else be.zeros(16)
@@ -131,7 +136,7 @@ class ForestEngine(BatchEngine):
         d_uni, uoff = self._uniforms_all()
         self._set(NODES=self.d_nodes, N_NODES=self.n_nodes, META=self.d_meta, N_MSAS=M, FAILED=self.d_failed, ERR_FIRST=self.d_err,
                   POOL=self.d_pool, POOL_USED=0, ARENA=self.d_arena, MAX_NESTING=self.max_nesting, MIN_MATCH=self.L,
-                  FUSED_ENABLED=int(FUSED_VIEWS), N_INIT=N_INIT, HDR=self.d_hdr)
+                  FUSED_ENABLED=int(FUSED_VIEWS), N_INIT=N_INIT, HDR=self.d_hdr, HDR_HOST=self._hdr_buf)
         for k_, o_ in uoff.items():
             self.F[FI["UOFF"] + k_] = o_
         self._d_uni = d_uni
@@ -139,7 +144,7 @@ class ForestEngine(BatchEngine):
         while n:
             self.counters["levels"] += 1
             f0, n = self._forest_level(f0, n)
-            self._alive = {k: v for k, v in self._alive.items() if k in ("NODES", "META", "FAILED", "ERR_FIRST", "POOL", "ARENA", "HDR")}
+            self._alive = {k: v for k, v in self._alive.items() if k in ("NODES", "META", "FAILED", "ERR_FIRST", "POOL", "ARENA", "HDR", "HDR_HOST")}
         # per-locus policy: the locus is dropped, the batch goes on; the first failing view in frontier order names the error
         if M and len(ok):
             failed_dev = be.download(self.d_failed, np.int32, M) != 0

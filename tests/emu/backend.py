@@ -59,6 +59,10 @@ class EmuBackend(_Base):
         nbytes = int(count) * np.dtype(dtype).itemsize
         return buf[:nbytes].copy().view(dtype)
 
+    def host_visible(self, nbytes):
+        a = np.zeros(int(nbytes), np.uint8)
+        return a, a
+
     def download_async(self, buf, nbytes, slot=None):
         return buf[:int(nbytes)].copy(), (lambda: None)
 

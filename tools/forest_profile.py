@@ -45,3 +45,20 @@ print(f"device time in entry points: {tot:.2f} ms")
 for name, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
     gb = v["bytes"] / max(v["ms"], 1e-9) * 1e-6 if v["bytes"] else 0
     print(f"  {name:34s} {v['ms']:9.3f} ms {v['calls']:5d} calls  {gb:8.1f} GB/s")
+
+# ---- pipelined steps (what bench.py times): the text of step s is collected after step s+1 has been enqueued
+be.profile = None
+pending = None
+print("pipelined: run_forest / assemble(lazy) / collect of the previous step, ms")
+for s in range(steps + 3):
+    t0 = time.perf_counter()
+    eng.run_forest()
+    t1 = time.perf_counter()
+    fin = eng.assemble_prgs(as_bytes=True, lazy=True)
+    t2 = time.perf_counter()
+    if pending is not None:
+        prgs = pending()
+        n_ok = sum(p is not None for p in prgs); chars = sum(len(p) for p in prgs if p is not None)
+    t3 = time.perf_counter()
+    pending = fin
+    print(f"  step {s}: {1e3*(t1-t0):7.1f} {1e3*(t2-t1):7.1f} {1e3*(t3-t2):7.1f}   total {1e3*(t3-t0):7.1f}", flush=True)
