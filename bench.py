@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """bench.py — MSAs/sec of the from_msa hot path on MI355X (BASELINE.json metric).
 
-A step = one pass of the hot path (whole recursion forest + PRG string emission) over one batch of synthetic
-config-C alignments (the 30k-gene pan-genome shape of BASELINE.json: ~100 seqs x 1-3 kb, generator in
-make_prg_amd/utils/synthetic.py, seeds 0..batch-1 on every rank) that is already resident in HBM.  Each rank owns
-`--batch` alignments (weak scaling: the directory of MSAs shards with no data-path collective) and builds them with
-`--workers` host worker processes that share the rank's GPU (the reference's own parallelism is a process pool over
-alignments; here the processes overlap the array-at-a-time host control of one sub-batch with the kernels of the others).
+A step = one pass of the hot path (whole recursion forest + PRG string emission) over the synthetic config-C set (the
+30k-gene pan-genome shape of BASELINE.json: ~100 seqs x 1-3 kb, generator in make_prg_amd/utils/synthetic.py, seeds
+0..batch-1) that is already resident in HBM.  With N ranks the SAME `--batch` alignments are sharded over the ranks by
+size (longest-processing-time greedy on rows x columns, the rule the CLI uses on file sizes): strong scaling, BASELINE
+config 3, no data-path collective (`--weak`: every rank builds all of them).  A rank builds its shard with `--workers` host
+worker processes that share the rank's GPU; every table of the recursion lives on the device (make_prg_amd/forest.py), so ONE
+worker keeps the device busy — more workers only fill the gaps at the host's waits (`single_worker` in the line: the same run
+with one worker).
 
 What the one JSON line holds (rank 0):
   value            K timed steps of all workers, HIP-event timing OFF, barrier + synchronize on both sides, MAX over ranks
@@ -24,7 +26,7 @@ between; they leave the start barrier in lockstep (every worker in the same phas
 assemble PRG strings) and fall out of phase over the first steps, so few steps measure the transient, not the rate
 (3 steps: ~745 ms per step, 12 steps: ~670 ms on the same box, profiles/r02/README.md).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workers P] [--streams S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workers P] [--streams S] [--weak]
     --workers 0 runs the same loop inside this process (profiler runs: nothing forks)
 """
 import argparse
@@ -68,6 +70,25 @@ def _oracle_one(seed):
     orc.encode_prg_bytes(prg)
     orc.gfa_text(prg)
     return t1 - t0, time.perf_counter() - t1
+
+
+def lpt_parts(seeds, n_parts):
+    """Size-balanced split of the alignments `seeds` into n_parts lists: longest-processing-time greedy on rows x columns
+    (make_prg_amd.subcommands.from_msa.balanced_parts does the same on file sizes); deterministic."""
+    import heapq
+    from make_prg_amd.utils.synthetic import config_shape
+    cost = []
+    for sd in seeds:
+        S, C, _ = config_shape("C", sd)
+        cost.append((-S * C, sd))
+    cost.sort()
+    heap = [(0, p) for p in range(n_parts)]
+    parts = [[] for _ in range(n_parts)]
+    for neg, sd in cost:
+        load, p = heapq.heappop(heap)
+        parts[p].append(sd)
+        heapq.heappush(heap, (load - neg, p))
+    return [sorted(p) for p in parts]
 
 
 def make_batch(seeds, procs):
@@ -255,11 +276,15 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=30000,
-                    help="alignments per GPU per step (default: the whole 30k-gene pan-genome of BASELINE.json, ~15 GB of HBM)")
+                    help="alignments of the job per step (default: the whole 30k-gene pan-genome of BASELINE.json, ~15 GB of HBM); "
+                         "sharded over the ranks unless --weak")
+    ap.add_argument("--weak", action="store_true", help="every rank builds all --batch alignments (weak scaling)")
+    ap.add_argument("--no-single-worker-leg", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
-    ap.add_argument("--workers", type=int, default=10, help="host worker processes per GPU (each owns a sub-batch)")
+    ap.add_argument("--workers", type=int, default=4, help="host worker processes per GPU (each owns a sub-batch); capped by the "
+                                                           "CPUs this rank may use")
     ap.add_argument("--streams", type=int, default=1, help="host threads / HIP streams per worker process")
     ap.add_argument("--profile-timed", action="store_true",
                     help="HIP events around every entry point INSIDE the timed region too (diagnostic; adds event traffic)")
@@ -299,19 +324,22 @@ def main():
     # host workers are forked BEFORE this process initialises the GPU (a forked HIP context is unusable)
     import multiprocessing as mp
     ctx = mp.get_context("fork")
-    W = max(0, min(args.workers, args.batch))
+    all_seeds = list(range(args.batch))
+    # strong scaling (default): the job's alignments are sharded over the ranks by size; every rank verifies its own seeds
+    seeds = all_seeds if (args.weak or world == 1) else lpt_parts(all_seeds, world)[rank]
+    W = max(0, min(args.workers, len(seeds)))
     if W > 1:          # stay inside the host: the CPUs this process may use and a quarter of the free memory (~4 GiB per worker)
         try:
             avail_kib = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1])
         except Exception:
             avail_kib = 64 << 20
         W = max(1, min(W, max(1, (ncpu - 1) // max(world, 1)), int(avail_kib / (4 << 20) / 4 / max(world, 1))))
-    seeds = list(range(args.batch))           # the same alignments on every rank: each rank's work is verifiable
     gen_procs = args.gen_procs or max(1, min(16, ncpu // (max(W, 1) * max(world, 1))))
+    parts = lpt_parts(seeds, W) if W > 1 else [seeds]
     conns, procs, th = [], [], None
     for w in range(W):
         a, b = ctx.Pipe()
-        pr = ctx.Process(target=_worker, args=(b, local_rank, seeds[w::W], args.streams, gen_procs))
+        pr = ctx.Process(target=_worker, args=(b, local_rank, parts[w], args.streams, gen_procs))
         pr.start()
         conns.append(a); procs.append(pr)
     if W == 0:          # --workers 0: the same worker loop on a thread of this process (rocprofv3 runs: nothing forks)
@@ -382,7 +410,11 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
-    total_msas = args.batch * world * args.steps
+    n_local = torch.tensor([len(seeds)], dtype=torch.float64, device=device if dist_backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(n_local, op=dist.ReduceOp.SUM)
+    msas_per_step = int(n_local.item())          # strong: --batch; weak: --batch x ranks
+    total_msas = msas_per_step * args.steps
     value = total_msas / dt_max
 
     # ---- outside the timed region: check what was timed, byte for byte
@@ -390,7 +422,7 @@ def main():
     verified = None
     if all(b is not None for b in bad_lists):
         bad = sorted(x for b in bad_lists for x in b)
-        verified = dict(loci=args.batch, mismatches=len(bad), first_bad=bad[:10],
+        verified = dict(loci=len(seeds), mismatches=len(bad), first_bad=bad[:10],
                         against="tests/golden/config_c_digests.bin (oracle: sha256(PRG)[:8] + node count per seed)")
     if world > 1:
         flag = torch.tensor([0 if verified is None else verified["mismatches"]], dtype=torch.float64,
@@ -419,6 +451,31 @@ def main():
                    output_bytes=sum(p["out_bytes"] for p in parts))
     for c in conns:
         c.send(("quit", None))
+    for pr in procs:
+        pr.join(timeout=60)
+
+    # ---- the same measurement with ONE host worker process (a fresh child process; this one's workers have left the device)
+    single = None
+    if rank == 0 and world == 1 and W > 1 and not args.no_single_worker_leg:
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--workers", "1", "--steps", str(max(3, args.steps // 2)), "--warmup", "2",
+               "--batch", str(args.batch), "--no-cpu-baseline", "--no-end-to-end", "--no-single-worker-leg"]
+        try:
+            line = subprocess.run(cmd, capture_output=True, text=True, timeout=900, check=True).stdout.strip().splitlines()[-1]
+            one = json.loads(line)
+            single = dict(value=one["value"], ms_per_step=one["ms_per_step"], steps=one["steps"],
+                          fraction_of_value=round(one["value"] / value, 4),
+                          exclusive_pass=one["roofline"]["exclusive_pass"], verified_mismatches=one["config"]["verified"]["mismatches"])
+        except Exception as err:          # reported, not hidden
+            single = dict(error=f"{type(err).__name__}: {err}"[:300])
+
+    # whole-job counters (strong scaling: a rank's workers only saw its shard)
+    keys = ("launches", "fits", "cells_all", "cells_clustered", "kmeans_bytes", "syncs")
+    cvec = torch.tensor([float(counters.get(k_, 0)) for k_ in keys], dtype=torch.float64, device=device if dist_backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(cvec, op=dist.ReduceOp.SUM)
+    for k_, v_ in zip(keys, cvec.tolist()):
+        counters[k_] = v_
 
     if rank == 0:
         prof = excl["prof"] or {"mprg_kmeans_restarts": dict(calls=0, ms=0.0, bytes=0.0)}
@@ -440,14 +497,14 @@ def main():
         # exactly these kernel sources; otherwise null
         traffic = traffic_note = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_summary.json")))
             if pm.get("source_digest") == source_digest():
                 # the PMC passes profile a different batch (8192 alignments in one process), so their bytes per launch are
                 # not this pass's: what carries over is HBM bytes / algorithmic bytes of the entry point, measured there
                 ratio = pm["entry_points"][name]["traffic_over_algorithmic"]
                 traffic = round(ratio * top["algorithmic_bytes_per_launch"], 1)
                 traffic_note = (f"{ratio} x algorithmic bytes: (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes of {name} in the PMC "
-                                f"passes of the same sources (profiles/r02/pmc_summary.json, source_digest {pm['source_digest']})")
+                                f"passes of the same sources (profiles/r03/pmc_summary.json, source_digest {pm['source_digest']})")
         except Exception:
             pass
         roof = dict(bound="hbm", kernel=top["kernel"], entry_point=name, achieved=top["achieved_GBps"] or 0.0,
@@ -457,18 +514,24 @@ def main():
                     measured="exclusive pass: one worker process alone on the device, one stream, "
                              f"{excl['loci']} alignments, HIP events around every entry point on the launch stream",
                     exclusive_pass=dict(wall_ms=round(excl["wall_ms"], 3), device_ms=round(dev_ms, 3),
-                                        kmeans_fits=excl["counters"]["fits"], launches=excl["counters"]["launches"]),
+                                        wall_over_device=round(excl["wall_ms"] / max(dev_ms, 1e-9), 3),
+                                        kmeans_fits=excl["counters"]["fits"], launches=excl["counters"]["launches"],
+                                        host_waits=excl["counters"].get("syncs", 0)),
                     kernels=[kern(n_, d_) for n_, d_ in ranked[:6]])
         out = {
             "metric": "MSAs/sec (from_msa, whole node) on 30k-gene pan-genome",
             "value": round(value, 3), "unit": "MSAs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1000.0 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1000.0 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None, "dtype": "u8 (+f64 KMeans)", "data": "synthetic",
             "config": {"workload": "C: 30k-gene pan-genome shape (S~N(100,20) in [20,300] rows x 1000-3000 cols, "
-                                   "SURVEY.md §8d generator, seeds 0..batch-1), -N 5 -L 7; one step = one resident batch per GPU",
-                       "batch_per_gpu": args.batch, "parallelism": f"shard{world}", "host_worker_processes_per_gpu": W,
+                                   "SURVEY.md §8d generator, seeds 0..batch-1), -N 5 -L 7; one step = every alignment of the job, "
+                                   "resident, sharded over the ranks by size (--weak: all of them on every rank)",
+                       "alignments_per_step": msas_per_step, "alignments_rank0": len(seeds), "parallelism": f"shard{world}",
+                       "host_worker_processes_per_gpu": W, "cpus_rank0": ncpu, "single_worker": single,
                        "streams_per_worker": args.streams, "event_timing_in_timed_region": bool(args.profile_timed),
-                       "step_includes": "recursion forest on device + host control + PRG string emission + download",
+                       "step_includes": "recursion forest (kernels + device-side bookkeeping; the host sizes buffers from one header per "
+                                        "step) + PRG text laid out and written on the device + its copy to pinned host memory",
+                       "host_waits_per_step": counters.get("syncs", 0) / args.steps,
                        "ingest_s_excluded": round(t_ing, 3), "loci_built_last_step": n_ok,
                        "levels": counters["levels"] / args.steps, "launches_per_step": counters["launches"] / args.steps,
                        "kmeans_fits_per_step": counters["fits"] / args.steps,
@@ -481,8 +544,6 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    for pr in procs:
-        pr.join(timeout=30)
     if th is not None:
         th.join(timeout=30)
     if world > 1:
