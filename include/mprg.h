@@ -176,9 +176,20 @@ int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, in
  * k_max, 0))).  The problems' workspaces (`ws`, prob[WS_OFF]) then only need their common part
  * (mprg_kmeans_workspace_doubles(D, V, k_max, 0)), written by mprg_kmeans_prepare and read-only here.  Outputs as
  * mprg_kmeans_restarts + mprg_kmeans_select; kinfo field 2 is ignored. */
-int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
-                    const double *xcounts, double *ws, double *slot_ws, int64_t slot_stride_doubles, int n_slots,
-                    int32_t *next_fit, int32_t *labels, double *km_info, int32_t *km_status, void *stream);
+int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
+                    const double *uniforms_dev, const double *xcounts, double *ws, double *slot_ws, int64_t slot_stride_doubles,
+                    int n_slots, int32_t *next_fit, int32_t *labels, double *km_info, int32_t *km_status, void *stream);
+/* A11, the WAVE form of mprg_kmeans_fit for small fits (the rule in pan-genome alignments: ~14 sequences x ~90 k-mers): one
+ * wavefront per fit, its restarts one after the other with the running restart's whole state in a compact LDS region, the best
+ * restart chosen incrementally, predict() at the end.  Same results as the other forms.  fit_list (optional, also in
+ * mprg_kmeans_fit's one-workgroup-per-fit form): int32 rows of kinfo this launch handles (n_fits of them); outputs
+ * (km_info, km_status) stay indexed by the kinfo row.  lds_class: mprg_kmeans_wave_class(D, V, k) of every fit of the launch
+ * (0..3: 7.4 / 13.6 / 23.8 / 38.1 KB regions; -1: the fit needs the workgroup form).  The final centres of the best restart
+ * pass through restart slot 0 of the problem's workspace. */
+int mprg_kmeans_wave_class(int64_t D, int64_t V, int k);
+int mprg_kmeans_fit_wave(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int lds_class, int n_init,
+                         const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
+                         int32_t *km_status, void *stream);
 /* fills out[n] with numpy.random.RandomState(seed).random_sample(n) (host memory; MT19937) */
 void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
 
@@ -268,6 +279,7 @@ enum {
   MPRG_F_LEVELS = 60 /* HOST int64 [levels][4]: first node, nodes, reps_pos, reps_len (device addresses or 0) */, MPRG_F_N_LEVELS = 61,
   MPRG_F_VALS_MSA = 62 /* int64 [alignments][cols]: col 0 becomes tree base, then text base */, MPRG_F_VALS_NODE = 63,
   MPRG_F_VALS_POS = 64, MPRG_F_N_SITES = 65, MPRG_F_JOBS = 66, MPRG_F_OUT = 67, MPRG_F_MSA_BASE = 68, MPRG_F_UOFF = 69 /* .. 79: offset of k's uniforms, k = 2..10 */,
+  MPRG_F_FIT_LISTS = 81 /* int32 [5][P]: the round's fits per launch list (hdr 86-90) */,
   MPRG_F_HDR_HOST = 80 /* optional: host-visible (pinned) int64 [MPRG_FOREST_HDR]; every step that fills MPRG_F_HDR copies it there */,
   MPRG_F_FIELDS = 96
 };
@@ -299,8 +311,10 @@ int mprg_forest_sizes_count(const int64_t *F, void *stream);
 int mprg_forest_sizes_fill(const int64_t *F, void *stream);
 /* S6  the clustering loop's control step before round k (k = 2 .. 11; cluster_sequences.py:256-274): settles round k-1 from
  *     km_info / km_status / out_further, writes the kinfo of round k (k = 0: the problem is done, its workgroups return).
- *     hdr (accumulated from mprg_forest_sizes_count on): 80 fits run, 81 KMeans algorithmic bytes (double), 82 unsupported fit,
- *     84 cells visited by the rounds' mprg_cluster_further (double); 83 (reset per call) problems still active. */
+ *     hdr (accumulated from mprg_forest_sizes_count on): 80 fits run, 81 / 85 KMeans algorithmic bytes of the fits with / without
+ *     a wave-form LDS class (doubles), 82 unsupported fit,
+ *     84 cells visited by the rounds' mprg_cluster_further (double); reset per call: 83 problems still active, 86-89 fits of
+ *     round k for mprg_kmeans_fit_wave per LDS class, 90 fits for mprg_kmeans_fit (listed in MPRG_F_FIT_LISTS). */
 int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream);
 /* S7  after the loop: hdr: 0 new MultiClusterNodes, 1 their rows, 2 their children.  _fill: tables of mprg_split_children;
  *     _split_children (after it): the nodes become cluster nodes, their children are appended at MPRG_F_N_NODES. */

@@ -27,11 +27,16 @@ static int check_launch(const char *name) {
 
 #define BLOCK_VIEW 256
 #include <stdlib.h>
-static int env_threads(const char *name, int dflt) {
+// workgroup-size knobs of a few kernels (diagnostic runs): read ONCE, when the library is loaded
+static int env_threads(const char *name, int dflt, int hi = 1024) {
   const char *e = getenv(name);
   const int v = e ? atoi(e) : dflt;
-  return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : dflt;
+  return (v >= 64 && v <= hi && v % 64 == 0) ? v : dflt;
 }
+static const int g_pf_threads = env_threads("MPRG_PF_THREADS", BLOCK_VIEW);
+static const int g_dd_threads = env_threads("MPRG_DD_THREADS", BLOCK_VIEW, 512);   // k_ungap_dedupe packs three 10-bit counters per scan
+static const int g_km_threads = env_threads("MPRG_KM_THREADS", 256);
+static const int g_kp_threads = env_threads("MPRG_KP_THREADS", 0);
 
 extern "C" {
 
@@ -84,7 +89,7 @@ int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *ro
     LAUNCH(k_partition, n_other, BLOCK_VIEW, stream, other_list, arena, views, rowidx, mask, min_match_length, maxrun, stack,
            ivflag, iv, n_iv, status, view_out);
   if (n_fused > 0)
-    LAUNCH(k_partition_fused, n_fused, env_threads("MPRG_PF_THREADS", BLOCK_VIEW), stream, fused_list, arena, views, rowidx, min_match_length, iv, n_iv, status,
+    LAUNCH(k_partition_fused, n_fused, g_pf_threads, stream, fused_list, arena, views, rowidx, min_match_length, iv, n_iv, status,
            view_out);
   if (view_out) {                                  // the packed list of all triples of the call
     if (!iv_packed || !iv_count) return fail("mprg_partition: view_out needs iv_packed and iv_count");
@@ -101,7 +106,7 @@ int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t 
                       int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, uint8_t *gcodes, void *stream) {
   if (n_views <= 0) return 0;
   LAUNCH(k_ungap_hash, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, ucodes, hashes, ulen, gcodes);
-  LAUNCH(k_ungap_dedupe, n_views, env_threads("MPRG_DD_THREADS", BLOCK_VIEW), stream, arena, views, rowidx, kmer_size, ucodes, (const uint8_t *)gcodes, hashes, ulen, rep_u, rep_g,
+  LAUNCH(k_ungap_dedupe, n_views, g_dd_threads, stream, arena, views, rowidx, kmer_size, ucodes, (const uint8_t *)gcodes, hashes, ulen, rep_u, rep_g,
          d_of_row, s_of_row, reps_pos, reps_len, seqrow, occ_off, summary);
   return check_launch("k_ungap_dedupe");
 }
@@ -153,7 +158,7 @@ int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts,
       }
     }
     // LDS decides how many of these workgroups a CU holds: the big classes get the threads the small ones get from residency
-    const int prep_threads = env_threads("MPRG_KP_THREADS", lds_bytes > 64 * 1024 ? 1024 : (lds_bytes > 24 * 1024 ? 512 : 256));
+    const int prep_threads = g_kp_threads ? g_kp_threads : (lds_bytes > 64 * 1024 ? 1024 : (lds_bytes > 24 * 1024 ? 512 : 256));
     LAUNCH_LDS(k_kmeans_prepare_lds, n_lds, prep_threads, lds_bytes, stream, lds_list, prob, xcounts, ws);
   }
   return check_launch("k_kmeans_prepare");
@@ -163,28 +168,49 @@ int mprg_kmeans_restarts(const int64_t *prob, const int32_t *kinfo, int n_fits, 
                          const double *xcounts, double *ws, int32_t *km_status, void *stream) {
   if (n_fits <= 0) return 0;
   if (n_init > KM_RMAX) return fail("n_init must be <= 16");
-  LAUNCH(k_kmeans_restart, n_fits, env_threads("MPRG_KM_THREADS", 256), stream, prob, kinfo, n_init, uniforms_dev, xcounts,
+  LAUNCH(k_kmeans_restart, n_fits, g_km_threads, stream, prob, kinfo, n_init, uniforms_dev, xcounts,
          ws, km_status);
   return check_launch("k_kmeans_restart");
 }
 
-int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *uniforms_dev,
+int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init, const double *uniforms_dev,
                     const double *xcounts, double *ws, double *slot_ws, int64_t slot_stride_doubles, int n_slots,
                     int32_t *next_fit, int32_t *labels, double *km_info, int32_t *km_status, void *stream) {
   if (n_fits <= 0) return 0;
   if (n_init > KM_RMAX) return fail("n_init must be <= 16");
   static_assert(KM_SEL_LABELS * sizeof(int32_t) <= KM_XL_BYTES, "the selection's label staging lives in the restarts' LDS pool");
   if (!slot_ws) {                      // no scratch slots: one workgroup per fit on the restart regions of the problems' workspaces
-    LAUNCH(k_kmeans_restart_select, n_fits, env_threads("MPRG_KM_THREADS", 256), stream, prob, kinfo, n_init, uniforms_dev, xcounts,
+    LAUNCH(k_kmeans_restart_select, n_fits, g_km_threads, stream, prob, kinfo, fit_list, n_init, uniforms_dev, xcounts,
            ws, labels, km_info, km_status);
     return check_launch("k_kmeans_restart_select");
   }
+  if (fit_list) return fail("mprg_kmeans_fit: the persistent form takes no fit list");
   if (n_slots <= 0 || slot_stride_doubles <= 0) return fail("mprg_kmeans_fit: no scratch slots");
   if (hipMemsetAsync(next_fit, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return fail("memset");
   const int grid = n_fits < n_slots ? n_fits : n_slots;
-  LAUNCH(k_kmeans_fit, grid, env_threads("MPRG_KM_THREADS", 256), stream, prob, kinfo, n_fits, n_init, uniforms_dev, xcounts, ws,
+  LAUNCH(k_kmeans_fit, grid, g_km_threads, stream, prob, kinfo, n_fits, n_init, uniforms_dev, xcounts, ws,
          slot_ws, (long long)slot_stride_doubles, next_fit, labels, km_info, km_status);
   return check_launch("k_kmeans_fit");
+}
+
+int mprg_kmeans_wave_class(int64_t D, int64_t V, int k) { return (k < 2 || k > KM_KMAX) ? -1 : km_wave_class_host(D, V, k); }
+
+int mprg_kmeans_fit_wave(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int lds_class, int n_init,
+                         const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
+                         int32_t *km_status, void *stream) {
+  if (n_fits <= 0) return 0;
+  if (n_init > KM_RMAX) return fail("n_init must be <= 16");
+#define KMW_LAUNCH(DBL) hipLaunchKernelGGL((k_kmeans_fit_wave<DBL>), dim3((unsigned)n_fits), dim3(64), 0, (hipStream_t)stream, prob, kinfo, \
+                                           fit_list, n_init, uniforms_dev, xcounts, ws, labels, km_info, km_status)
+  switch (lds_class) {
+    case 0: KMW_LAUNCH(KMW_C0); break;
+    case 1: KMW_LAUNCH(KMW_C1); break;
+    case 2: KMW_LAUNCH(KMW_C2); break;
+    case 3: KMW_LAUNCH(KMW_C3); break;
+    default: return fail("mprg_kmeans_fit_wave: lds_class must be 0..3 (mprg_kmeans_wave_class)");
+  }
+#undef KMW_LAUNCH
+  return check_launch("k_kmeans_fit_wave");
 }
 
 int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *xcounts,
@@ -323,9 +349,10 @@ int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream) {
   if (P <= 0) return 0;
   if (k < 2 || k > KM_KMAX + 1) return fail("mprg_forest_kloop_advance: k out of range");
   if (hipMemsetAsync(FHDR + 83, 0, sizeof(int64_t), (hipStream_t)stream) != hipSuccess) return fail("memset");
+  if (hipMemsetAsync(FHDR + 86, 0, 5 * sizeof(int64_t), (hipStream_t)stream) != hipSuccess) return fail("memset");
   LAUNCH(k_kl_advance, KF_GRID(P), 256, stream, P, k, (int)F[MPRG_F_N_INIT], FP(const int64_t, MPRG_F_PTAB), FP(const int64_t, MPRG_F_SUB),
          FP(int32_t, MPRG_F_NUM_CLUSTERS), FP(int32_t, MPRG_F_ACTIVE), FP(int32_t, MPRG_F_KINFO), FP(const double, MPRG_F_KM_INFO), FP(int32_t, MPRG_F_KM_STATUS),
-         FP(const int32_t, MPRG_F_FURTHER), (int)F[MPRG_F_UOFF + (k <= KM_KMAX ? k : 0)], FHDR);
+         FP(const int32_t, MPRG_F_FURTHER), (int)F[MPRG_F_UOFF + (k <= KM_KMAX ? k : 0)], FP(int32_t, MPRG_F_FIT_LISTS), FHDR);
   return kf_publish(F, stream, "k_kl_advance");
 }
 int mprg_forest_splits_count(const int64_t *F, void *stream) {

@@ -40,7 +40,9 @@ _F_NAMES = ("NODES N_NODES META N_MSAS FAILED ERR_FIRST POOL POOL_USED ARENA MAX
             "KM_INFO KM_STATUS SPT SP SPLITNODE CHILD_SIZES NSPLITS ASM ROOT_OF SPECIAL_LIST SPECIAL_CAP PATCH N_PATCH LEVELS "
             "N_LEVELS VALS_MSA VALS_NODE VALS_POS N_SITES JOBS OUT MSA_BASE UOFF").split()
 FI = {name: i for i, name in enumerate(_F_NAMES)}
-FI["HDR_HOST"] = 80
+FI["HDR_HOST"], FI["FIT_LISTS"] = 80, 81
+WAVE_CLASSES = 4                         # LDS classes of mprg_kmeans_fit_wave (+ the workgroup form)
+KMEANS_WAVE = os.environ.get("MPRG_KMEANS_WAVE", "1") != "0"     # 0: every fit in the workgroup form (diagnostic)
 F_FIELDS = 96
 PREPARE_CLASSES = 4                      # LDS classes of mprg_kmeans_prepare (+ the global-memory form)
 
@@ -274,27 +276,53 @@ class ForestEngine(BatchEngine):
         # ---- S6: cluster_sequences.py:256-274 for all problems of the level, one k per round, no host decision in between:
         #      the control step settles the previous round on the device; a retired problem's workgroups return at once
         km_events, cf_events = [], []
+        d_fl = be.empty(4 * (WAVE_CLASSES + 1) * P)
+        self._set(FIT_LISTS=d_fl)
+        fit_args = (be.ptr(self._d_uni), be.ptr(d_x), be.ptr(d_ws))
+        out_args = (be.ptr(d_labels), be.ptr(d_info), be.ptr(d_st), be.stream)
         for k in range(2, MAX_CLUSTERS + 2):
-            hk = self._step("kloop_advance", k, n_hdr=HDR if k >= 4 else 0)
-            if k > MAX_CLUSTERS or (hk is not None and hk[83] == 0):
+            hk = self._step("kloop_advance", k, n_hdr=HDR)
+            if k > MAX_CLUSTERS or hk[83] == 0:
                 break
-            be.call("mprg_kmeans_fit", be.ptr(d_ptab), be.ptr(d_kinfo), P, N_INIT, be.ptr(self._d_uni), be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, 0,
-                    be.ptr(d_labels), be.ptr(d_info), be.ptr(d_st), be.stream)
-            km_events.append(self._last_event("mprg_kmeans_fit"))
+            # the round's fits, already sorted into launch lists by the control step: wave form by LDS class (one wavefront per
+            # fit, restart state in LDS), workgroup form for fits beyond the largest class
+            counts = [int(x) for x in hk[86:86 + WAVE_CLASSES + 1]]
+            if not KMEANS_WAVE:
+                be.call("mprg_kmeans_fit", be.ptr(d_ptab), be.ptr(d_kinfo), None, P, N_INIT, *fit_args, 0, 0, 0, 0, *out_args)
+                km_events.append(self._last_event("mprg_kmeans_fit"))
+                self.counters["launches"] += 1
+            else:
+                for c, n_c in enumerate(counts):
+                    if not n_c:
+                        continue
+                    lst = be.ptr(d_fl) + 4 * c * P
+                    if c < WAVE_CLASSES:
+                        be.call("mprg_kmeans_fit_wave", be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, c, N_INIT, *fit_args, *out_args)
+                        km_events.append(self._last_event("mprg_kmeans_fit_wave"))
+                    else:
+                        be.call("mprg_kmeans_fit", be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, 0, 0, 0, 0, *out_args)
+                        km_events.append(self._last_event("mprg_kmeans_fit"))
+                    self.counters["launches"] += 1
             self._cluster_further(d_sub, d_ptab, P, k, dd, d_labels, d_assign, d_wc, n_wc, d_wr, n_wr, d_scratch, d_further, d_info, d_kinfo)
             cf_events.append(self._last_event("mprg_cluster_further"))
-            self.counters["launches"] += 1
         # ---- S7: MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
         self._scratch(P)
         h = self._step("splits_count", n_hdr=HDR)
         n_splits, rows_sp, n_child = (int(x) for x in h[:3])
-        fits, km_bytes, cf_cells = int(h[80]), float(h[81:82].view(np.float64)[0]), float(h[84:85].view(np.float64)[0])
+        fits, cf_cells = int(h[80]), float(h[84:85].view(np.float64)[0])
+        kb_wave, kb_wg = float(h[81:82].view(np.float64)[0]), float(h[85:86].view(np.float64)[0])
+        km_bytes = kb_wave + kb_wg
         if h[82]:
             raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
                             "is not restated on the device; refusing to continue with a possibly different result")
         self.counters["fits"] += fits
         self.counters["kmeans_bytes"] += km_bytes
-        self._credit(km_events, km_bytes)              # algorithmic bytes are known only after the fits: 8 D V (iterations + n_init)
+        # algorithmic bytes are known only after the fits: 8 D V (iterations + n_init)
+        if KMEANS_WAVE:
+            self._credit([e for e in km_events if e and e[0] == "mprg_kmeans_fit_wave"], kb_wave)
+            self._credit([e for e in km_events if e and e[0] == "mprg_kmeans_fit"], kb_wg)
+        else:
+            self._credit(km_events, km_bytes)
         self._credit(cf_events, cf_cells)
         if n_splits == 0:
             return 0

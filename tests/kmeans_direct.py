@@ -8,7 +8,9 @@ def run_kmeans_fits(be, fits, n_init=10, path="global", n_slots=3):
     """path: "global" = mprg_kmeans_restarts + mprg_kmeans_select ("global-nocounts": without the count matrices, i.e. every
     fit reads the centred matrix from its workspace) (one restart region per problem, two launches);
     "one-launch" = mprg_kmeans_fit without scratch slots (a workgroup per fit: restarts, then selection);
-    "fit" = mprg_kmeans_fit (persistent workgroups, per-restart arrays in `n_slots` scratch slots, selection fused)."""
+    "fit" = mprg_kmeans_fit (persistent workgroups, per-restart arrays in `n_slots` scratch slots, selection fused);
+    "wave" = mprg_kmeans_fit_wave by LDS class through fit lists (one wavefront per fit, restart state in LDS); the fits without
+    a class take mprg_kmeans_fit with a fit list."""
     groups = {}
     for idx, f in enumerate(fits):
         groups.setdefault(f["k"], []).append(idx)
@@ -45,11 +47,22 @@ def run_kmeans_fits(be, fits, n_init=10, path="global", n_slots=3):
             W = lambda D, V, r: int(be.lib.mprg_kmeans_workspace_doubles(int(D), int(V), 10, r))
             stride = max(W(ptab[i, 1], ptab[i, 7], n_init) - W(ptab[i, 1], ptab[i, 7], 0) for i in range(P))
             d_slots = be.empty(8 * stride * n_slots)
-            be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws),
+            be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), None, P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws),
                     be.ptr(d_slots), stride, n_slots, be.ptr(be.empty(16)), be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
         elif path == "one-launch":
-            be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, 0,
+            be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), None, P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, 0,
                     be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
+        elif path == "wave":
+            cls = np.asarray([be.lib.mprg_kmeans_wave_class(int(ptab[i, 1]), int(ptab[i, 7]), k) for i in range(P)])
+            for c in sorted(set(cls.tolist())):
+                lst = np.nonzero(cls == c)[0].astype(np.int32)
+                d_l = be.upload(lst)
+                if c >= 0:
+                    be.call("mprg_kmeans_fit_wave", be.ptr(d_p), be.ptr(d_ki), be.ptr(d_l), len(lst), c, n_init, be.ptr(d_u), be.ptr(d_x),
+                            be.ptr(d_ws), be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
+                else:
+                    be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), be.ptr(d_l), len(lst), n_init, be.ptr(d_u), be.ptr(d_x),
+                            be.ptr(d_ws), 0, 0, 0, 0, be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
         else:
             be.call("mprg_kmeans_restarts", be.ptr(d_p), be.ptr(d_ki), P, n_init, be.ptr(d_u), 0 if path == "global-nocounts" else be.ptr(d_x),
                     be.ptr(d_ws), be.ptr(d_st1), be.stream)
