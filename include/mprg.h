@@ -187,6 +187,13 @@ int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, const int32_t *fi
  * (0..3: 7.4 / 13.6 / 23.8 / 38.1 KB regions; -1: the fit needs the workgroup form).  The final centres of the best restart
  * pass through restart slot 0 of the problem's workspace. */
 int mprg_kmeans_wave_class(int64_t D, int64_t V, int k);
+/* A11, the workgroup form for SMALL fits: 128-thread workgroups with a trimmed static LDS (8 KB pool; small_class 0 also a
+ * 6 x 6 centre-centre table, i.e. k <= 6), so that 6-8 fits are resident per CU instead of 4.  mprg_kmeans_small_class(D, V, k,
+ * n_init): 0 / 1, or -1 if the fit needs the general form (mprg_kmeans_fit).  Arguments as mprg_kmeans_fit_wave. */
+int mprg_kmeans_small_class(int64_t D, int64_t V, int k, int n_init);
+int mprg_kmeans_fit_small(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int small_class, int n_init,
+                          const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
+                          int32_t *km_status, void *stream);
 int mprg_kmeans_fit_wave(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int lds_class, int n_init,
                          const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
                          int32_t *km_status, void *stream);
@@ -279,7 +286,8 @@ enum {
   MPRG_F_LEVELS = 60 /* HOST int64 [levels][4]: first node, nodes, reps_pos, reps_len (device addresses or 0) */, MPRG_F_N_LEVELS = 61,
   MPRG_F_VALS_MSA = 62 /* int64 [alignments][cols]: col 0 becomes tree base, then text base */, MPRG_F_VALS_NODE = 63,
   MPRG_F_VALS_POS = 64, MPRG_F_N_SITES = 65, MPRG_F_JOBS = 66, MPRG_F_OUT = 67, MPRG_F_MSA_BASE = 68, MPRG_F_UOFF = 69 /* .. 79: offset of k's uniforms, k = 2..10 */,
-  MPRG_F_FIT_LISTS = 81 /* int32 [5][P]: the round's fits per launch list (hdr 86-90) */,
+  MPRG_F_FIT_LISTS = 81 /* int32 [7][P]: the round's fits per launch list (hdr 86-92) */,
+  MPRG_F_KM_MODE = 82 /* bit 0: small fits in the wave form, bit 1: small fits in the small workgroup form */,
   MPRG_F_HDR_HOST = 80 /* optional: host-visible (pinned) int64 [MPRG_FOREST_HDR]; every step that fills MPRG_F_HDR copies it there */,
   MPRG_F_FIELDS = 96
 };
@@ -311,10 +319,11 @@ int mprg_forest_sizes_count(const int64_t *F, void *stream);
 int mprg_forest_sizes_fill(const int64_t *F, void *stream);
 /* S6  the clustering loop's control step before round k (k = 2 .. 11; cluster_sequences.py:256-274): settles round k-1 from
  *     km_info / km_status / out_further, writes the kinfo of round k (k = 0: the problem is done, its workgroups return).
- *     hdr (accumulated from mprg_forest_sizes_count on): 80 fits run, 81 / 85 KMeans algorithmic bytes of the fits with / without
- *     a wave-form LDS class (doubles), 82 unsupported fit,
+ *     hdr (accumulated from mprg_forest_sizes_count on): 80 fits run, 81 / 85 / 93 KMeans algorithmic bytes of the fits run in
+ *     the wave / general / small workgroup form (doubles), 82 unsupported fit,
  *     84 cells visited by the rounds' mprg_cluster_further (double); reset per call: 83 problems still active, 86-89 fits of
- *     round k for mprg_kmeans_fit_wave per LDS class, 90 fits for mprg_kmeans_fit (listed in MPRG_F_FIT_LISTS). */
+ *     round k for mprg_kmeans_fit_wave per LDS class, 90 fits for mprg_kmeans_fit, 91 / 92 for mprg_kmeans_fit_small class 0 / 1
+ *     (listed in MPRG_F_FIT_LISTS; which forms are used: MPRG_F_KM_MODE). */
 int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream);
 /* S7  after the loop: hdr: 0 new MultiClusterNodes, 1 their rows, 2 their children.  _fill: tables of mprg_split_children;
  *     _split_children (after it): the nodes become cluster nodes, their children are appended at MPRG_F_N_NODES. */

@@ -35,6 +35,8 @@ SIGNATURES = {
     "mprg_kmeans_fit": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int64, c_int] + [c_void_p] * 5),
     "mprg_kmeans_wave_class": (c_int, [c_int64, c_int64, c_int]),
     "mprg_kmeans_fit_wave": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7),
+    "mprg_kmeans_small_class": (c_int, [c_int64, c_int64, c_int, c_int]),
+    "mprg_kmeans_fit_small": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7),
     "mprg_kmeans_select": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 5),
     "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int] + [c_void_p] * 6),
     "mprg_split_children": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 7),

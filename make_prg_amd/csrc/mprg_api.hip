@@ -213,6 +213,27 @@ int mprg_kmeans_fit_wave(const int64_t *prob, const int32_t *kinfo, const int32_
   return check_launch("k_kmeans_fit_wave");
 }
 
+int mprg_kmeans_small_class(int64_t D, int64_t V, int k, int n_init) {
+  if (k < 2 || k > KM_KMAX || n_init > KMS_RMAX || n_init * D > KMS_LAB8) return -1;
+  long long vp = (V + 3) & ~3LL; if (((vp >> 2) & 1) == 0) vp += 4;
+  if (8 * ((V + 1) & ~1LL) + D * vp > KMS_POOL || (long long)n_init * 5 * D * 8 > KMS_POOL) return -1;
+  return k <= 6 ? 0 : 1;
+}
+
+int mprg_kmeans_fit_small(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int small_class, int n_init,
+                          const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
+                          int32_t *km_status, void *stream) {
+  if (n_fits <= 0) return 0;
+  if (n_init > KMS_RMAX) return fail("mprg_kmeans_fit_small: n_init must be <= 10");
+#define KMS_LAUNCH(KCH) hipLaunchKernelGGL((k_kmeans_restart_select_small<KCH>), dim3((unsigned)n_fits), dim3(128), 0, (hipStream_t)stream, prob, \
+                                           kinfo, fit_list, n_init, uniforms_dev, xcounts, ws, labels, km_info, km_status)
+  if (small_class == 0) KMS_LAUNCH(36);
+  else if (small_class == 1) KMS_LAUNCH(KM_KMAX * KM_KMAX);
+  else return fail("mprg_kmeans_fit_small: small_class must be 0 or 1 (mprg_kmeans_small_class)");
+#undef KMS_LAUNCH
+  return check_launch("k_kmeans_restart_select_small");
+}
+
 int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *xcounts,
                        double *ws, int32_t *labels, double *km_info, void *stream) {
   if (n_fits <= 0) return 0;
@@ -349,8 +370,8 @@ int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream) {
   if (P <= 0) return 0;
   if (k < 2 || k > KM_KMAX + 1) return fail("mprg_forest_kloop_advance: k out of range");
   if (hipMemsetAsync(FHDR + 83, 0, sizeof(int64_t), (hipStream_t)stream) != hipSuccess) return fail("memset");
-  if (hipMemsetAsync(FHDR + 86, 0, 5 * sizeof(int64_t), (hipStream_t)stream) != hipSuccess) return fail("memset");
-  LAUNCH(k_kl_advance, KF_GRID(P), 256, stream, P, k, (int)F[MPRG_F_N_INIT], FP(const int64_t, MPRG_F_PTAB), FP(const int64_t, MPRG_F_SUB),
+  if (hipMemsetAsync(FHDR + 86, 0, KL_LISTS * sizeof(int64_t), (hipStream_t)stream) != hipSuccess) return fail("memset");
+  LAUNCH(k_kl_advance, KF_GRID(P), 256, stream, P, k, (int)F[MPRG_F_N_INIT], (int)F[MPRG_F_KM_MODE], FP(const int64_t, MPRG_F_PTAB), FP(const int64_t, MPRG_F_SUB),
          FP(int32_t, MPRG_F_NUM_CLUSTERS), FP(int32_t, MPRG_F_ACTIVE), FP(int32_t, MPRG_F_KINFO), FP(const double, MPRG_F_KM_INFO), FP(int32_t, MPRG_F_KM_STATUS),
          FP(const int32_t, MPRG_F_FURTHER), (int)F[MPRG_F_UOFF + (k <= KM_KMAX ? k : 0)], FP(int32_t, MPRG_F_FIT_LISTS), FHDR);
   return kf_publish(F, stream, "k_kl_advance");

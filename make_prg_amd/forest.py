@@ -40,9 +40,12 @@ _F_NAMES = ("NODES N_NODES META N_MSAS FAILED ERR_FIRST POOL POOL_USED ARENA MAX
             "KM_INFO KM_STATUS SPT SP SPLITNODE CHILD_SIZES NSPLITS ASM ROOT_OF SPECIAL_LIST SPECIAL_CAP PATCH N_PATCH LEVELS "
             "N_LEVELS VALS_MSA VALS_NODE VALS_POS N_SITES JOBS OUT MSA_BASE UOFF").split()
 FI = {name: i for i, name in enumerate(_F_NAMES)}
-FI["HDR_HOST"], FI["FIT_LISTS"] = 80, 81
-WAVE_CLASSES = 4                         # LDS classes of mprg_kmeans_fit_wave (+ the workgroup form)
-KMEANS_WAVE = os.environ.get("MPRG_KMEANS_WAVE", "1") != "0"     # 0: every fit in the workgroup form (diagnostic)
+FI["HDR_HOST"], FI["FIT_LISTS"], FI["KM_MODE"] = 80, 81, 82
+# launch lists of a KMeans round (hdr 86..92): wave form by LDS class, general workgroup form, small workgroup form
+KM_LISTS = (("mprg_kmeans_fit_wave", 0), ("mprg_kmeans_fit_wave", 1), ("mprg_kmeans_fit_wave", 2), ("mprg_kmeans_fit_wave", 3),
+            ("mprg_kmeans_fit", None), ("mprg_kmeans_fit_small", 0), ("mprg_kmeans_fit_small", 1))
+# which forms small fits take: bit 0 wave form (measured slower on MI355X: profiles/r03/kmeans_forms.md), bit 1 small workgroups
+KM_MODE = int(os.environ.get("MPRG_KM_MODE", "2"))
 F_FIELDS = 96
 PREPARE_CLASSES = 4                      # LDS classes of mprg_kmeans_prepare (+ the global-memory form)
 
@@ -276,33 +279,26 @@ class ForestEngine(BatchEngine):
         # ---- S6: cluster_sequences.py:256-274 for all problems of the level, one k per round, no host decision in between:
         #      the control step settles the previous round on the device; a retired problem's workgroups return at once
         km_events, cf_events = [], []
-        d_fl = be.empty(4 * (WAVE_CLASSES + 1) * P)
-        self._set(FIT_LISTS=d_fl)
+        d_fl = be.empty(4 * len(KM_LISTS) * P)
+        self._set(FIT_LISTS=d_fl, KM_MODE=KM_MODE)
         fit_args = (be.ptr(self._d_uni), be.ptr(d_x), be.ptr(d_ws))
         out_args = (be.ptr(d_labels), be.ptr(d_info), be.ptr(d_st), be.stream)
         for k in range(2, MAX_CLUSTERS + 2):
             hk = self._step("kloop_advance", k, n_hdr=HDR)
             if k > MAX_CLUSTERS or hk[83] == 0:
                 break
-            # the round's fits, already sorted into launch lists by the control step: wave form by LDS class (one wavefront per
-            # fit, restart state in LDS), workgroup form for fits beyond the largest class
-            counts = [int(x) for x in hk[86:86 + WAVE_CLASSES + 1]]
-            if not KMEANS_WAVE:
-                be.call("mprg_kmeans_fit", be.ptr(d_ptab), be.ptr(d_kinfo), None, P, N_INIT, *fit_args, 0, 0, 0, 0, *out_args)
-                km_events.append(self._last_event("mprg_kmeans_fit"))
+            # the round's fits, already sorted into launch lists by the control step
+            for c, (entry, cls) in enumerate(KM_LISTS):
+                n_c = int(hk[86 + c])
+                if not n_c:
+                    continue
+                lst = be.ptr(d_fl) + 4 * c * P
+                if cls is None:
+                    be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, 0, 0, 0, 0, *out_args)
+                else:
+                    be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, cls, N_INIT, *fit_args, *out_args)
+                km_events.append(self._last_event(entry))
                 self.counters["launches"] += 1
-            else:
-                for c, n_c in enumerate(counts):
-                    if not n_c:
-                        continue
-                    lst = be.ptr(d_fl) + 4 * c * P
-                    if c < WAVE_CLASSES:
-                        be.call("mprg_kmeans_fit_wave", be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, c, N_INIT, *fit_args, *out_args)
-                        km_events.append(self._last_event("mprg_kmeans_fit_wave"))
-                    else:
-                        be.call("mprg_kmeans_fit", be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, 0, 0, 0, 0, *out_args)
-                        km_events.append(self._last_event("mprg_kmeans_fit"))
-                    self.counters["launches"] += 1
             self._cluster_further(d_sub, d_ptab, P, k, dd, d_labels, d_assign, d_wc, n_wc, d_wr, n_wr, d_scratch, d_further, d_info, d_kinfo)
             cf_events.append(self._last_event("mprg_cluster_further"))
         # ---- S7: MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
@@ -310,19 +306,17 @@ class ForestEngine(BatchEngine):
         h = self._step("splits_count", n_hdr=HDR)
         n_splits, rows_sp, n_child = (int(x) for x in h[:3])
         fits, cf_cells = int(h[80]), float(h[84:85].view(np.float64)[0])
-        kb_wave, kb_wg = float(h[81:82].view(np.float64)[0]), float(h[85:86].view(np.float64)[0])
-        km_bytes = kb_wave + kb_wg
+        kb = {"mprg_kmeans_fit_wave": float(h[81:82].view(np.float64)[0]), "mprg_kmeans_fit": float(h[85:86].view(np.float64)[0]),
+              "mprg_kmeans_fit_small": float(h[93:94].view(np.float64)[0])}
+        km_bytes = sum(kb.values())
         if h[82]:
             raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
                             "is not restated on the device; refusing to continue with a possibly different result")
         self.counters["fits"] += fits
         self.counters["kmeans_bytes"] += km_bytes
         # algorithmic bytes are known only after the fits: 8 D V (iterations + n_init)
-        if KMEANS_WAVE:
-            self._credit([e for e in km_events if e and e[0] == "mprg_kmeans_fit_wave"], kb_wave)
-            self._credit([e for e in km_events if e and e[0] == "mprg_kmeans_fit"], kb_wg)
-        else:
-            self._credit(km_events, km_bytes)
+        for entry, nbytes in kb.items():
+            self._credit([e for e in km_events if e and e[0] == entry], nbytes)
         self._credit(cf_events, cf_cells)
         if n_splits == 0:
             return 0

@@ -51,7 +51,7 @@ def test_fits_with_many_samples():
         lab, dbg = orc.kmeans_fit_predict(M, k, want_debug=True)
         fits.append(dict(shape=[D, V], counts_i16_hex=M.astype("<i2").tobytes().hex(), k=k, labels=lab.tolist(),
                          inertia=float(dbg["inertia"]).hex(), n_iter=dbg["n_iter"]))
-    for path, slots in (("global", 0), ("one-launch", 0), ("wave", 0), ("fit", 1), ("fit", 64)):
+    for path, slots in (("global", 0), ("one-launch", 0), ("wave", 0), ("small", 0), ("fit", 1), ("fit", 64)):
         got = run_kmeans_fits(EmuBackend(), fits, path=path, n_slots=slots)
         for g, f in zip(got, fits):
             assert not g["status"] & 2
@@ -77,6 +77,7 @@ def test_relocation_with_wide_matrices():
     check(EmuBackend(), fits)
     check(EmuBackend(), fits, path="one-launch")
     check(EmuBackend(), fits, path="wave")
+    check(EmuBackend(), fits, path="small")
     check(EmuBackend(), fits, path="fit", n_slots=2)
 
 
@@ -91,7 +92,7 @@ def test_fits_outside_the_lds_count_form():
         lab, dbg = orc.kmeans_fit_predict(M, k, want_debug=True)
         fits.append(dict(shape=[D, V], counts_i16_hex=M.astype("<i2").tobytes().hex(), k=k, labels=lab.tolist(),
                          inertia=float(dbg["inertia"]).hex(), n_iter=dbg["n_iter"]))
-    for path, slots in (("global", 0), ("global-nocounts", 0), ("one-launch", 0), ("wave", 0), ("fit", 2)):
+    for path, slots in (("global", 0), ("global-nocounts", 0), ("one-launch", 0), ("wave", 0), ("small", 0), ("fit", 2)):
         got = run_kmeans_fits(EmuBackend(), fits, path=path, n_slots=slots)
         for g, f in zip(got, fits):
             assert not g["status"] & 2
