@@ -38,7 +38,8 @@ enum { MPRG_CODE_GAP = 4, MPRG_CODE_N = 11, MPRG_N_CODES = 12 };
 enum { MPRG_IV_MATCH = 0, MPRG_IV_NONMATCH = 1 /* bit 0 of a triple's type word */,
        MPRG_IV_PURE = 2 /* bit 1: match interval straight from the scan, view without N / ambiguity codes */ };
 /* per-view status bits written by mprg_partition */
-enum { MPRG_ST_PARTITION_ERROR = 1, MPRG_ST_ALL_N_SLICE = 2 };
+enum { MPRG_ST_PARTITION_ERROR = 1, MPRG_ST_ALL_N_SLICE = 2,
+       MPRG_ST_BAD_LAUNCH = 4 /* a view of fused_list does not satisfy the fused launch shape: a host error, not a property of the data */ };
 /* per-fit status bits written by the KMeans kernels */
 enum { MPRG_KM_RELOCATED = 1 /* an empty cluster was relocated (info) */, MPRG_KM_UNSUPPORTED = 2 /* error */ };
 
@@ -357,6 +358,31 @@ long long mprg_gfa_text_host(const char *prg, long long n, char *out, long long 
 enum { MPRG_RAGGED_ALIGNMENT = -5 };
 long long mprg_fasta_scan_host(const char *text, long long n, long long *n_records, long long *seq_len);
 long long mprg_fasta_fill_host(const char *text, long long n, uint8_t *matrix, long long seq_len, long long *title_spans);
+
+/* (f)-2 BATCH stages of the driver, HOST functions with their own threads (reference: one worker process per locus,
+ * utils/io_utils.py:17-49, utils/input_output_files.py:73-162).
+ * mprg_ingest_*: a list of FASTA files (paths: n_files NUL-terminated strings back to back) is read and scanned by n_threads
+ * threads; info = 5 int64 per file {status (0, MPRG_NOT_PLAIN_STRING: gzip or bytes the Python parser takes,
+ * MPRG_RAGGED_ALIGNMENT, MPRG_INGEST_UNREADABLE, MPRG_INGEST_NO_RECORDS), rows, columns, bytes of its titles joined by '\n',
+ * flags (MPRG_INGEST_DUP_IDS, MPRG_INGEST_HAS_N)}; _fill writes file i's upper-cased matrix at arena + raw_off[i] (the caller's
+ * pinned upload buffer; raw_off[i] < 0: skip) and its titles at titles + title_off[i].
+ * mprg_encode_*: the batch's PRG text (one buffer; locus i = [base[i], base[i] + len[i]), len < 0: none) -> binary PRG words and
+ * GFA bytes per locus (_sizes; -1: the one-pass encoders do not cover this string), then the encodings at the caller's offsets
+ * and the CRC-32 of the three future zip members {PRG text, binary PRG, GFA text} per locus (_fill). */
+enum { MPRG_INGEST_UNREADABLE_FILE = -6, MPRG_INGEST_NO_RECORDS_FILE = -7 };
+enum { MPRG_INGEST_FLAG_DUP_IDS = 1, MPRG_INGEST_FLAG_HAS_N = 2 };
+void *mprg_ingest_open_host(const char *paths, long long n_files, int n_threads);
+void mprg_ingest_info_host(void *handle, long long *info);
+void mprg_ingest_fill_host(void *handle, uint8_t *arena, const long long *raw_off, char *titles, const long long *title_off,
+                           int n_threads);
+long long mprg_ingest_text_host(void *handle, long long i, const char **text);
+void mprg_ingest_close_host(void *handle);
+void mprg_encode_sizes_host(const char *prg, const long long *base, const long long *len, long long n, int n_threads,
+                            int want_bin, int want_gfa, long long *bin_words, long long *gfa_bytes);
+void mprg_encode_fill_host(const char *prg, const long long *base, const long long *len, long long n, int n_threads,
+                           uint32_t *bin_out, const long long *bin_off, const long long *bin_words, char *gfa_out,
+                           const long long *gfa_off, const long long *gfa_bytes, uint32_t *crc);
+void mprg_crc32_ranges_host(const char *buf, const long long *off, const long long *len, long long n, int n_threads, uint32_t *crc);
 
 #ifdef __cplusplus
 }

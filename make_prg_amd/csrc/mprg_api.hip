@@ -15,6 +15,7 @@
 #include "k_emit.inc"
 #include "k_forest.inc"
 #include "host_encoders.inc"
+#include "host_batch.inc"
 
 static thread_local char g_err[512] = "";
 static int fail(const char *what) { snprintf(g_err, sizeof g_err, "%s", what); return -1; }
@@ -83,7 +84,9 @@ int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *ro
                    const int32_t *other_list, int n_other, void *stream) {
   if (n_views <= 0) return 0;
   if (!fused_list && !other_list) { n_fused = 0; n_other = n_views; }
-  else if (n_fused + n_other != n_views) return fail("mprg_partition: the two view lists must cover the views");
+  else if (n_fused < 0 || n_other < 0 || n_fused + n_other != n_views) return fail("mprg_partition: the two view lists must cover the views");
+  else if ((n_fused > 0 && !fused_list) || (n_other > 0 && !other_list)) return fail("mprg_partition: a view list is missing");
+  if (min_match_length < 1) return fail("mprg_partition: min_match_length must be positive");
   if (n_work_rows > 0) LAUNCH(k_gap_runs, n_work_rows, GR_ROWS, stream, arena, views, rowidx, work_rows, mask, maxrun);
   if (n_other > 0)
     LAUNCH(k_partition, n_other, BLOCK_VIEW, stream, other_list, arena, views, rowidx, mask, min_match_length, maxrun, stack,

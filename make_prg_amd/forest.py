@@ -157,9 +157,12 @@ class ForestEngine(BatchEngine):
             if len(new):
                 err = be.download(self.d_err, np.uint64, M)
                 for mi in new.tolist():
+                    code = int(err[mi]) & 3
+                    if code == 3:
+                        raise MprgError("mprg_partition was given a view for its fused launch shape that does not fit it")
                     self.failed[mi] = True
                     self.errors[mi] = (SequenceCurationError("All sequences in this slice contained N. Redo sequence curation.")
-                                       if int(err[mi]) & 2 else PartitioningError("Failed interval partitioning"))
+                                       if code == 2 else PartitioningError("Failed interval partitioning"))
 
     # ------------------------------------------------------------------------------------------------ level
     def _forest_level(self, f0: int, n: int):

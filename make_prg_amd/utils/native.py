@@ -17,6 +17,14 @@ HOST_SIGNATURES = {
     "mprg_gfa_text_host": (_LL, [_P, _LL, _P, _LL]),
     "mprg_fasta_scan_host": (_LL, [_P, _LL, _P, _P]),
     "mprg_fasta_fill_host": (_LL, [_P, _LL, _P, _LL, _P]),
+    "mprg_ingest_open_host": (_P, [_P, _LL, ctypes.c_int]),
+    "mprg_ingest_info_host": (None, [_P, _P]),
+    "mprg_ingest_fill_host": (None, [_P, _P, _P, _P, _P, ctypes.c_int]),
+    "mprg_ingest_text_host": (_LL, [_P, _LL, _P]),
+    "mprg_ingest_close_host": (None, [_P]),
+    "mprg_encode_sizes_host": (None, [_P, _P, _P, _LL, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "mprg_encode_fill_host": (None, [_P, _P, _P, _LL, ctypes.c_int] + [_P] * 7),
+    "mprg_crc32_ranges_host": (None, [_P, _P, _P, _LL, ctypes.c_int, _P]),
 }
 _lib = None
 _tried = False

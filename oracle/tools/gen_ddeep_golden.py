@@ -6,7 +6,10 @@ Expected values come from the oracle (pinned to the real reference by gen_golden
 unmodified reference on the same input (container only, slow) and records whether its PRG is identical.
 Writes tests/golden/ddeep.json: hashes of the PRG / .bin / .gfa / recursion tree / prg_index + counters.
 
-    python -m oracle.tools.gen_ddeep_golden [--reference]"""
+A second fixture of another seed, shape and nesting limit: `--name ddeep2 --seed 3 --rows 900 --cols 2600 --nesting 3`
+(tests/golden/ddeep2.json).
+
+    python -m oracle.tools.gen_ddeep_golden [--reference] [--name NAME --seed S --rows R --cols C --nesting N]"""
 import hashlib
 import json
 import os
@@ -16,6 +19,11 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 S, C, SEED, N, L = 2000, 4000, 0, 7, 7
+NAME = "ddeep"
+
+
+def _arg(flag, default, conv=int):
+    return conv(sys.argv[sys.argv.index(flag) + 1]) if flag in sys.argv else default
 
 
 def sha(obj):
@@ -27,6 +35,8 @@ def sha(obj):
 
 
 def main():
+    global S, C, SEED, N, NAME
+    S, C, SEED, N, NAME = _arg("--rows", S), _arg("--cols", C), _arg("--seed", SEED), _arg("--nesting", N), _arg("--name", NAME, str)
     want_reference = "--reference" in sys.argv
     if want_reference:
         import oracle.refshim.bootstrap as rb
@@ -58,15 +68,15 @@ def main():
         import tempfile
         from pathlib import Path
         from make_prg.prg_builder import PrgBuilder
-        p = Path(tempfile.mkdtemp()) / "ddeep.fa"
+        p = Path(tempfile.mkdtemp()) / f"{NAME}.fa"
         p.write_text(text)
         t0 = time.time()
-        rb_ = PrgBuilder("ddeep", p, "fasta", N, L)
+        rb_ = PrgBuilder(NAME, p, "fasta", N, L)
         ref_prg = rb_.build_prg()
         out["reference"] = dict(seconds=round(time.time() - t0, 1), prg_identical=ref_prg == prg,
                                 next_node_id_identical=rb_.next_node_id == b.next_node_id)
-        assert ref_prg == prg, "the real reference disagrees with the oracle on Ddeep"
-    path = os.path.join(ROOT, "tests", "golden", "ddeep.json")
+        assert ref_prg == prg, "the real reference disagrees with the oracle on " + NAME
+    path = os.path.join(ROOT, "tests", "golden", NAME + ".json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out, indent=1))

@@ -33,7 +33,7 @@ def build_emu(force=False, defines=(), tag="") -> str:
                                "-I", os.path.join(HERE, "include"), '-DMPRG_BUILD_TAG="cpu emulation, tests only"',
                                "-fPIC", "-shared", "-Wno-unused-function", "-Wno-attributes", "-Wno-unknown-pragmas"] +
                               [f"-D{d}" for d in defines] +
-                              [os.path.join(SRC_DIR, "mprg_api.hip"), "-o", lib])
+                              ["-pthread", os.path.join(SRC_DIR, "mprg_api.hip"), "-o", lib, "-lz"])
     return lib
 
 

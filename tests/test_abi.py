@@ -56,3 +56,11 @@ def test_product_has_no_cpu_fallback():
     import pytest
     with pytest.raises(backend.MprgError):
         backend.HipBackend(0)
+    # the reference-shaped helper functions too: inputs of the kernels' domain need the device, nothing answers in its place
+    from make_prg_amd import device
+    from make_prg_amd.from_msa import cluster_sequences as cs
+    device.set_backend(None)
+    with pytest.raises(backend.MprgError):
+        cs.sequences_are_one_reference_like(["ACGT", "ACGA"])
+    with pytest.raises(backend.MprgError):
+        cs.cluster_further([["ACGT", "ACGA"], ["TTTT"]])

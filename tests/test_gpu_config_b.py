@@ -71,12 +71,14 @@ def test_full_config_against_oracle(oracle_results, cfg, lo, hi):
 
 def test_config_d_at_full_size_properties(oracle_results):
     """BASELINE.json config D: ONE alignment of 10 000 x 20 000 (200 MB per copy), -N 7 -L 7.  No oracle at this size:
-    size-independent checks — every allele non-empty, markers >= 5 and paired, and (the tree being a root with one
-    multi-allele leaf for this generator) the alleles are exactly the distinct ungapped input rows, each once."""
+    checks that hold for ANY recursion tree (tests/prg_walk.py) — the site markers nest, every site number is used once, and
+    every distinct ungapped input row is spelt by exactly ONE choice of alleles through the PRG — plus the node table's own
+    invariants (children contiguous, every node reachable once, leaves partition the root's columns along every path)."""
     from make_prg_amd.backend import HipBackend
-    from make_prg_amd.forest import ForestEngine
+    from make_prg_amd.forest import KIND_LEAF, ForestEngine
     from make_prg_amd.msa import MSA, Record
     from make_prg_amd.utils.synthetic import synth_rows
+    from tests.prg_walk import check_prg_spells_rows
     rows = synth_rows(0, 10_000, 20_000, 8)
     msa = MSA([Record(r, f"s{i}", f"s{i}") for i, r in enumerate(rows)])
     eng = ForestEngine(HipBackend(0), 7, 7)
@@ -84,12 +86,41 @@ def test_config_d_at_full_size_properties(oracle_results):
     eng.run_forest()
     prg = eng.assemble_prgs()[0]
     assert prg is not None and len(prg) > 10_000 * 19_000
-    check_markers(prg)
-    units = prg.split()
-    alleles = [u for u in units if not u.isdigit()]
-    assert all(int(u) >= 5 for u in units if u.isdigit())
-    distinct = {r.replace(b"-", b"").decode() for r in rows}
-    if eng.n_nodes == 2:
-        assert len(alleles) == len(distinct) and set(alleles) == distinct
-    else:                                   # a deeper tree: every input row must still be spelt by a path... at least
-        assert set("".join(alleles)) <= set("ACGT")      # the alphabet holds
+    n_rows = check_prg_spells_rows(prg, [r.decode() for r in rows])
+    assert n_rows == len({r.replace(b"-", b"") for r in rows})
+    t = eng.tab
+    n = eng.n_nodes
+    assert n >= 2 and int(eng.tree_sizes[0]) == n and sorted(eng.node_id.tolist()) == list(range(n))
+    kids = np.concatenate([np.arange(f, f + c) for f, c in zip(t["first_child"], t["n_child"]) if c > 0])
+    assert sorted(kids.tolist()) == list(range(1, n)), "every node but the root is the child of exactly one node"
+    assert (t["n_child"][t["kind"] == KIND_LEAF] == 0).all() and (t["n_child"][t["kind"] != KIND_LEAF] >= 2).all()
+    assert int(t["level"].max()) < 7
+
+
+def _oracle_text(args):
+    text, N = args
+    import oracle.from_msa_oracle as orc
+    prg, b, root = orc.build_locus_from_text(text, N, 7)
+    return prg, b.next_node_id
+
+
+def test_config_d_generator_subsamples_against_oracle():
+    """Row / column subsamples of the config-D alignment (the same generator stream), -N 7: PRG and node count against the
+    oracle, at sizes it finishes in seconds."""
+    import oracle.from_msa_oracle as orc
+    from make_prg_amd.backend import HipBackend
+    from make_prg_amd.forest import ForestEngine
+    from make_prg_amd.msa import load_alignment_text
+    from make_prg_amd.utils.synthetic import synth_rows
+    orc.build_kmeans_lib()
+    rows = synth_rows(0, 10_000, 20_000, 8)
+    texts = []
+    for r0, nr, c0, nc in ((0, 300, 0, 3000), (5000, 200, 12000, 5000), (17, 400, 400, 1500)):
+        texts.append("".join(f">s{i}\n{rows[i][c0:c0 + nc].decode()}\n" for i in range(r0, r0 + nr)))
+    want = [_oracle_text((t, 7)) for t in texts]
+    eng = ForestEngine(HipBackend(0), 7, 7)
+    eng.load([load_alignment_text(t) for t in texts])
+    eng.run_forest()
+    prgs = eng.assemble_prgs()
+    assert [p for p in prgs] == [w[0] for w in want]
+    assert [int(x) for x in eng.tree_sizes] == [w[1] for w in want]

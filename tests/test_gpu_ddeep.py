@@ -15,14 +15,18 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_deep_hierarchical_alignment_against_the_oracle_fixture():
+@pytest.mark.parametrize("fixture", ["ddeep.json", "ddeep2.json"])
+def test_deep_hierarchical_alignment_against_the_oracle_fixture(fixture):
+    """ddeep: 2 000 x 4 000, seed 0, -N 7; ddeep2: 900 x 2 600, seed 3, -N 3 (the nesting limit cuts the recursion short: the
+    deepest candidates become multi-allele leaves).  Both fixtures were confirmed by the REAL reference (their "reference" block)."""
     from make_prg_amd.backend import HipBackend
     from make_prg_amd.forest import ForestEngine
     from make_prg_amd.msa import load_alignment_text
     from make_prg_amd.utils.gfa import GFA_Output
     from make_prg_amd.utils.synthetic import synth_deep_fasta
-    with open(os.path.join(HERE, "golden", "ddeep.json")) as fh:
+    with open(os.path.join(HERE, "golden", fixture)) as fh:
         g = json.load(fh)
+    assert g["reference"]["prg_identical"] and g["reference"]["next_node_id_identical"]
     text = synth_deep_fasta(g["seed"], g["S"], g["C"])
     assert pc.sha(text) == g["fasta_sha256"], "the generator changed under the fixture"
     msa = load_alignment_text(text)
@@ -33,7 +37,7 @@ def test_deep_hierarchical_alignment_against_the_oracle_fixture():
     e = g["expect"]
     assert prg is not None and len(prg) == e["prg_len"] and pc.sha(prg) == e["prg_sha256"]
     # the engine skips fits whose result the reference computes and then discards (nesting exhausted, recursion_tree.py:453-456)
-    assert 0.9 * g["kmeans_fits"] <= int(eng.counters["fits"]) <= g["kmeans_fits"]
+    assert (0.9 if g["N"] >= 7 else 0.0) * g["kmeans_fits"] < int(eng.counters["fits"]) <= g["kmeans_fits"]
     assert pc.sha(pc.product_bin_bytes(prg)) == e["bin_sha256"]
     assert pc.sha(GFA_Output.gfa_text(prg)) == e["gfa_sha256"]
     tree = eng.tree_dump(0, msa.ids)
