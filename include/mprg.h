@@ -288,6 +288,8 @@ enum {
   MPRG_F_VALS_MSA = 62 /* int64 [alignments][cols]: col 0 becomes tree base, then text base */, MPRG_F_VALS_NODE = 63,
   MPRG_F_VALS_POS = 64, MPRG_F_N_SITES = 65, MPRG_F_JOBS = 66, MPRG_F_OUT = 67, MPRG_F_MSA_BASE = 68, MPRG_F_UOFF = 69 /* .. 79: offset of k's uniforms, k = 2..10 */,
   MPRG_F_FIT_LISTS = 81 /* int32 [7][P]: the round's fits per launch list (hdr 86-92) */,
+  MPRG_F_INDEX_OUT = 83 /* optional int32 [jobs][3]: the PRG index {start, end, node id}, per locus contiguous */,
+  MPRG_F_EX_RECORDS = 84, MPRG_F_EX_ROWS = 85,
   MPRG_F_KM_MODE = 82 /* bit 0: small fits in the wave form, bit 1: small fits in the small workgroup form */,
   MPRG_F_HDR_HOST = 80 /* optional: host-visible (pinned) int64 [MPRG_FOREST_HDR]; every step that fills MPRG_F_HDR copies it there */,
   MPRG_F_FIELDS = 96
@@ -337,6 +339,13 @@ int mprg_forest_split_children(const int64_t *F, void *stream);
 int mprg_forest_assemble_special(const int64_t *F, void *stream);
 int mprg_forest_assemble_layout(const int64_t *F, void *stream);
 int mprg_forest_assemble_emit(const int64_t *F, void *stream);
+/* KE  export for the update data structure (after _layout): per node, at its preorder place (MPRG_F_VALS_MSA[alignment] + node
+ *     id), 8 int32 {parent's node id, kind, nesting level, rows (-1: all rows of the alignment, -2: its parent's rows), first of
+ *     its rows in the locus's slice of MPRG_F_EX_ROWS, first column, columns, alleles}; MPRG_F_EX_ROWS: the MSA rows of the nodes
+ *     that own a list (children of cluster nodes), per locus contiguous.  _count: hdr 0 = entries of MPRG_F_EX_ROWS (uses
+ *     MPRG_F_VALS_POS). */
+int mprg_forest_export_count(const int64_t *F, void *stream);
+int mprg_forest_export_fill(const int64_t *F, void *stream);
 
 /* (f)-1 output encoders, HOST functions (host pointers), one pass over a PRG string as PrgBuilder emits it.
  * reference make_prg/utils/prg_encoder.py:44-91 and make_prg/utils/gfa.py:16-109.
@@ -382,7 +391,9 @@ void mprg_encode_sizes_host(const char *prg, const long long *base, const long l
 void mprg_encode_fill_host(const char *prg, const long long *base, const long long *len, long long n, int n_threads,
                            uint32_t *bin_out, const long long *bin_off, const long long *bin_words, char *gfa_out,
                            const long long *gfa_off, const long long *gfa_bytes, uint32_t *crc);
-void mprg_crc32_ranges_host(const char *buf, const long long *off, const long long *len, long long n, int n_threads, uint32_t *crc);
+/* CRC-32 of zip members given as pieces (member i = pieces first[i] .. first[i+1]-1; piece k = len[k] bytes at address addr[k]) */
+void mprg_crc32_members_host(const long long *addr, const long long *len, const long long *first, long long n_members, int n_threads,
+                             uint32_t *crc);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,8 @@ SIGNATURES = {
     "mprg_forest_assemble_layout": (c_int, [c_void_p, c_void_p]),
     "mprg_forest_assemble_emit": (c_int, [c_void_p, c_void_p]),
     "mprg_forest_kloop_advance": (c_int, [c_void_p, c_int, c_void_p]),
+    "mprg_forest_export_count": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_export_fill": (c_int, [c_void_p, c_void_p]),
     "mprg_random_sample_host": (None, [c_uint32, c_int, c_void_p]),
     "mprg_prg_encode_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p]),
     "mprg_fasta_scan_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
@@ -71,7 +73,7 @@ SIGNATURES = {
     "mprg_ingest_close_host": (None, [c_void_p]),
     "mprg_encode_sizes_host": (None, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mprg_encode_fill_host": (None, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int] + [c_void_p] * 7),
-    "mprg_crc32_ranges_host": (None, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p]),
+    "mprg_crc32_members_host": (None, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p]),
 }
 
 
@@ -167,6 +169,22 @@ class HipBackend(_Base):
             return np.empty(0, dtype)
         return buf[:nbytes].cpu().numpy().view(dtype)
 
+    def pinned(self, nbytes: int, key):
+        """(buffer, uint8 array over it): page-locked host memory for uploads, kept and reused per `key` (grown when needed:
+        page-locking is slow, ~1 s per 6 GB)."""
+        if not hasattr(self, "_pinned_up"):
+            self._pinned_up = {}
+        t = self._pinned_up.get(key)
+        if t is None or t.numel() < nbytes:
+            t = self._pinned_up[key] = self.torch.empty(max(int(nbytes) + (int(nbytes) >> 3), 1 << 20), dtype=self.torch.uint8, pin_memory=True)
+        return t, t.numpy()
+
+    def upload_from(self, pinned_buf, nbytes: int):
+        """Device copy of the first nbytes of a pinned() buffer, enqueued on the compute stream (no staging copy)."""
+        if nbytes == 0:
+            return self.empty(16)
+        return pinned_buf[:int(nbytes)].to(self.device, non_blocking=True)
+
     def host_visible(self, nbytes: int):
         """(buffer whose ptr() kernels may write, uint8 array over the same memory): page-locked host memory — hipHostMalloc
         memory is mapped into the device's address space — for results a few words long: the device stores them, the host waits
@@ -174,24 +192,25 @@ class HipBackend(_Base):
         t = self.torch.zeros(int(nbytes), dtype=self.torch.uint8, pin_memory=True)
         return t, t.numpy()
 
-    def download_async(self, buf, nbytes: int, slot: Optional[int] = None):
+    def download_async(self, buf, nbytes: int, group: int = 0):
         """Start copying buf[:nbytes] into a PINNED host buffer on the backend's copy stream, behind everything enqueued on the
         compute stream so far; returns (uint8 array over the pinned buffer, wait()).  The array's contents are valid after
-        wait(); successive calls alternate between two pinned buffers (slot None), so the copy of one batch overlaps the kernels
-        of the next and a result stays valid until the second following call.  utils/io_utils.py:105-110 writes these bytes to files."""
+        wait(); successive calls of one `group` alternate between two pinned buffers, so the copy of one batch overlaps the
+        kernels of the next and a result stays valid until the second following call of that group.
+        utils/io_utils.py:105-110 writes these bytes to files."""
         torch = self.torch
         nbytes = int(nbytes)
         if not hasattr(self, "_pinned"):
-            self._pinned, self._copy_stream, self._next_slot = {}, torch.cuda.Stream(self.device), 0
-        if slot is None:
-            slot, self._next_slot = self._next_slot, self._next_slot ^ 1
-        host = self._pinned.get(slot)
+            self._pinned, self._copy_stream, self._parity = {}, torch.cuda.Stream(self.device), {}
+        par = self._parity.get(group, 0)
+        self._parity[group] = par ^ 1
+        host = self._pinned.get((group, par))
         if host is None or host.numel() < nbytes:
             # both buffers at once: page-locking GBs takes longer than a whole batch, better paid during warm-up
-            for q in (slot, slot ^ 1):
-                if self._pinned.get(q) is None or self._pinned[q].numel() < nbytes:
-                    self._pinned[q] = torch.empty(max(nbytes + (nbytes >> 3), 1 << 20), dtype=torch.uint8, pin_memory=True)
-            host = self._pinned[slot]
+            for q in (par, par ^ 1):
+                if self._pinned.get((group, q)) is None or self._pinned[(group, q)].numel() < nbytes:
+                    self._pinned[(group, q)] = torch.empty(max(nbytes + (nbytes >> 3), 1 << 20), dtype=torch.uint8, pin_memory=True)
+            host = self._pinned[(group, par)]
         self._copy_stream.wait_stream(self.stream_obj)
         with torch.cuda.stream(self._copy_stream):
             if nbytes:

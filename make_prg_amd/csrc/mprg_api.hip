@@ -430,7 +430,7 @@ int mprg_forest_assemble_layout(const int64_t *F, void *stream) {
   for (int l = nl - 2; l >= 0; --l) if (LV[4 * l + 1] > 0) LAUNCH(k_as_up, KF_GRID(LV[4 * l + 1]), 256, stream, nodes, (long long)LV[4 * l], (long long)LV[4 * l + 1], A, (int)A_TOTAL);
   LAUNCH(k_as_msa_len, KF_GRID(M), 256, stream, M, root_of, failed, (const int64_t *)A, mb);
   if (kf_scan(mb, M, 1, FHDR, tmp, stream) != 0) return fail("scan");
-  LAUNCH(k_as_job_count, KF_GRID(n), 256, stream, n, (const int64_t *)A, vn);
+  LAUNCH(k_as_job_count, KF_GRID(n), 256, stream, nodes, n, (const int64_t *)A, (const int64_t *)vm, vn);
   if (kf_scan(vn, n, 1, FHDR + 1, tmp, stream) != 0) return fail("scan");
   return kf_publish(F, stream, "k_as_layout");
 }
@@ -442,13 +442,32 @@ int mprg_forest_assemble_emit(const int64_t *F, void *stream) {
   int64_t *A = FP(int64_t, MPRG_F_ASM);
   const int64_t *LV = (const int64_t *)(uintptr_t)F[MPRG_F_LEVELS];
   const int nl = (int)F[MPRG_F_N_LEVELS];
-  LAUNCH(k_as_root_start, KF_GRID(M), 256, stream, M, root_of, failed, A, FP(const int64_t, MPRG_F_MSA_BASE));
+  LAUNCH(k_as_root_start, KF_GRID(M), 256, stream, M, root_of, failed, A, FP(int64_t, MPRG_F_MSA_BASE), FP(const int64_t, MPRG_F_VALS_MSA),
+         FP(const int64_t, MPRG_F_VALS_NODE));
   for (int l = 0; l + 1 < nl; ++l) if (LV[4 * l + 1] > 0) LAUNCH(k_as_start, KF_GRID(LV[4 * l + 1]), 256, stream, nodes, (long long)LV[4 * l], (long long)LV[4 * l + 1], A);
   for (int l = 0; l < nl; ++l) if (LV[4 * l + 1] > 0)
     LAUNCH(k_as_leaf_jobs, KF_GRID(LV[4 * l + 1]), 256, stream, nodes, (long long)LV[4 * l], (long long)LV[4 * l + 1], failed, (const int64_t *)A,
-           FP(const int64_t, MPRG_F_VALS_NODE), FP(const int64_t, MPRG_F_META), FP(const int32_t, MPRG_F_POOL),
-           (const int32_t *)(uintptr_t)LV[4 * l + 2], (const int32_t *)(uintptr_t)LV[4 * l + 3], FP(int64_t, MPRG_F_JOBS), FP(uint8_t, MPRG_F_OUT));
+           FP(const int64_t, MPRG_F_VALS_NODE), FP(const int64_t, MPRG_F_VALS_MSA), FP(const int64_t, MPRG_F_MSA_BASE),
+           FP(const int64_t, MPRG_F_META), FP(const int32_t, MPRG_F_POOL),
+           (const int32_t *)(uintptr_t)LV[4 * l + 2], (const int32_t *)(uintptr_t)LV[4 * l + 3], FP(int64_t, MPRG_F_JOBS), FP(uint8_t, MPRG_F_OUT),
+           FP(int32_t, MPRG_F_INDEX_OUT));
   return check_launch("k_as_emit");
+}
+int mprg_forest_export_count(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_N_NODES];
+  if (n <= 0) return 0;
+  int64_t *vp = FP(int64_t, MPRG_F_VALS_POS);
+  LAUNCH(k_ex_count, KF_GRID(n), 256, stream, FP(const int64_t, MPRG_F_NODES), n, FP(const int64_t, MPRG_F_ASM), FP(const int64_t, MPRG_F_VALS_MSA), vp);
+  if (kf_scan(vp, n, 1, FHDR, FP(int64_t, MPRG_F_SCAN_TMP), stream) != 0) return fail("scan");
+  return kf_publish(F, stream, "k_ex_count");
+}
+int mprg_forest_export_fill(const int64_t *F, void *stream) {
+  const long long n = F[MPRG_F_N_NODES];
+  if (n <= 0) return 0;
+  LAUNCH(k_ex_fill, KF_GRID(n), 256, stream, FP(const int64_t, MPRG_F_NODES), n, FP(const int64_t, MPRG_F_ASM), FP(const int64_t, MPRG_F_VALS_MSA),
+         FP(const int64_t, MPRG_F_VALS_POS), FP(const int32_t, MPRG_F_POOL), FP(int32_t, MPRG_F_EX_RECORDS), FP(int32_t, MPRG_F_EX_ROWS),
+         FP(int64_t, MPRG_F_MSA_BASE));
+  return check_launch("k_ex_fill");
 }
 #undef FP
 #undef FHDR

@@ -40,7 +40,7 @@ _F_NAMES = ("NODES N_NODES META N_MSAS FAILED ERR_FIRST POOL POOL_USED ARENA MAX
             "KM_INFO KM_STATUS SPT SP SPLITNODE CHILD_SIZES NSPLITS ASM ROOT_OF SPECIAL_LIST SPECIAL_CAP PATCH N_PATCH LEVELS "
             "N_LEVELS VALS_MSA VALS_NODE VALS_POS N_SITES JOBS OUT MSA_BASE UOFF").split()
 FI = {name: i for i, name in enumerate(_F_NAMES)}
-FI["HDR_HOST"], FI["FIT_LISTS"], FI["KM_MODE"] = 80, 81, 82
+FI["HDR_HOST"], FI["FIT_LISTS"], FI["KM_MODE"], FI["INDEX_OUT"], FI["EX_RECORDS"], FI["EX_ROWS"] = 80, 81, 82, 83, 84, 85
 # launch lists of a KMeans round (hdr 86..92): wave form by LDS class, general workgroup form, small workgroup form
 KM_LISTS = (("mprg_kmeans_fit_wave", 0), ("mprg_kmeans_fit_wave", 1), ("mprg_kmeans_fit_wave", 2), ("mprg_kmeans_fit_wave", 3),
             ("mprg_kmeans_fit", None), ("mprg_kmeans_fit_small", 0), ("mprg_kmeans_fit_small", 1))
@@ -409,19 +409,28 @@ def _special_leaf_alleles(self: "ForestEngine", rows: np.ndarray) -> Dict[int, L
     return out
 
 
-def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool = False, lazy: bool = False):
+def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool = False, lazy: bool = False, export: bool = False):
     """PRG string of every alignment of the batch (None for loci dropped by the curation policy).  lazy: returns a function
     that waits for the text's copy to the host and returns the list — the copy then overlaps whatever the caller enqueues next
     (as_bytes views stay valid until the second following assemble_prgs of this engine's backend).
+    want_index: self.prg_index_entries(i) afterwards.  export: self.exported = the trees as per-locus slices of three arrays
+    (records, rows, PRG index: mprg_forest_export_* in include/mprg.h) for the update data structure.
     Device (mprg_forest_assemble_*): preorder ranks and site numbers, text lengths bottom-up, text offsets top-down over the
     node table; every leaf's alleles (mprg_emit_alleles) and every marker.  Host: the rare leaves with ambiguity codes.
     reference: PrgBuilder.build_prg prg_builder.py:100-105; traversals recursion_tree.py:194-201, :222-239, :266-300."""
     be = self.be
     n, M = self.n_nodes, len(self._msas)
-    self.prg_index_arrays = (np.zeros(0, np.int64),) * 3
+    self._index = None
+    self.exported = None
     if n == 0:
         self._asm, self._site_count = np.zeros((0, ASM_FIELDS), np.int64), np.zeros(M, np.int64)
-        return [None] * M
+        self._index, self._host_index = (np.zeros((0, 3), np.int32), np.zeros(M + 1, np.int64)), {}
+        if export:
+            self.exported = dict(records=np.zeros((0, 8), np.int32), rows=np.zeros(0, np.int32), node_bounds=np.zeros(M + 1, np.int64),
+                                 row_bounds=np.zeros(M + 1, np.int64), index=self._index[0], index_bounds=self._index[1])
+        nothing = lambda: [None] * M
+        nothing.buffer, nothing.base, nothing.length = np.zeros(0, np.uint8), np.zeros(M, np.int64), np.full(M, -1, np.int64)
+        return nothing if lazy else nothing()
     lv_arr = np.zeros((len(self.levels), 4), np.int64)
     for i, lv in enumerate(self.levels):
         lv_arr[i] = (lv["f0"], lv["n"], be.ptr(lv["reps_pos"]) if lv["reps_pos"] is not None else 0,
@@ -455,61 +464,85 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool =
     h = self._step("assemble_layout", n_hdr=2)
     total_chars, n_jobs = int(h[0]), int(h[1])
     d_out, d_jobs = be.empty(total_chars), be.empty(32 * max(n_jobs, 1))
-    self._set(OUT=d_out, JOBS=d_jobs)
+    d_index = be.empty(12 * max(n_jobs, 1)) if (want_index or export) else None
+    self._set(OUT=d_out, JOBS=d_jobs, INDEX_OUT=d_index)
     self._step("assemble_emit")
     if n_jobs:
         be.call("mprg_emit_alleles", be.ptr(self.d_arena), be.ptr(d_jobs), n_jobs, be.ptr(d_out), be.stream,
                 work=float(2 * total_chars))
         self.counters["launches"] += 1
-    # the text goes to a pinned host buffer on the copy stream; the caller may collect it later (lazy=True) so that the
-    # copy of this batch overlaps the kernels of the next one
-    msa_base = be.download(d_mbase, np.int64, VC * M).reshape(M, VC)[:, 0]       # (before the big copy: a copy queued behind
-    msa_len = np.diff(np.concatenate([msa_base, [total_chars]]))                  # 2.5 GB on the DMA engine waits for it)
+    d_rec = d_rows = None
+    n_ex_rows = 0
+    if export:
+        n_ex_rows = int(self._step("export_count", n_hdr=1)[0])
+        d_rec, d_rows = be.empty(32 * n), be.empty(4 * max(n_ex_rows, 1))
+        self._set(EX_RECORDS=d_rec, EX_ROWS=d_rows)
+        self._step("export_fill")
+    # small copies before the big asynchronous one (a copy queued behind 2.5 GB on the DMA engine waits for it).
+    # per alignment: start of its PRG in the batch text, first allele job / index entry, first node of its preorder run,
+    # first entry of its exported rows
+    mb = be.download(d_mbase, np.int64, VC * M).reshape(M, VC)
+    msa_base = mb[:, 0].copy()
+    msa_len = np.diff(np.concatenate([msa_base, [total_chars]]))
+
+    def bounds(col, total):
+        """[first, end) per alignment of a per-locus contiguous layout (alignments without a tree: empty)."""
+        first = col.copy()
+        nxt = total
+        for m in range(M - 1, -1, -1):               # (M is the batch's alignments: a short loop next to the work above)
+            if first[m] < 0:
+                first[m] = nxt
+            nxt = first[m]
+        return np.concatenate([first, [total]])
+
     self._asm = self._site_count = None
     self._d_asm, self._d_nsites = d_asm, d_nsites
-    index_parts = None
-    if want_index:      # prg_index: every allele of every leaf (recursion_tree.py:276-300)
-        A, t = self.asm, self.tab
-        jobs = be.download(d_jobs, np.int64, 4 * n_jobs).reshape(-1, 4)
-        dl = np.nonzero((t["kind"] == KIND_LEAF) & ~self.failed[t["msa"]] & (A[:, A_JOB] >= 0) & (A[:, A_NSEQ] > 0))[0]
-        jl = np.repeat(dl, A[dl, A_NSEQ])
-        js = jobs[:, 2] - msa_base[t["msa"][jl]]
-        index_parts = (jl, js, js + jobs[:, 3])
+    node_bounds = np.concatenate([mb[:, 2], [n]])
+    waits = []
+    if want_index or export:
+        ix_host, w_ = be.download_async(d_index, 12 * n_jobs, group=1)
+        waits.append(w_)
+        job_bounds = bounds(np.where(self.root_of >= 0, mb[:, 1], -1), n_jobs)
+        self._index = (ix_host.view(np.int32).reshape(-1, 3), job_bounds)
+    if export:
+        rec_host, w1 = be.download_async(d_rec, 32 * n, group=2)
+        rows_host, w2 = be.download_async(d_rows, 4 * n_ex_rows, group=3)
+        waits += [w1, w2]
+        self.exported = dict(records=rec_host.view(np.int32).reshape(-1, 8), rows=rows_host.view(np.int32), node_bounds=node_bounds,
+                             row_bounds=bounds(np.where(self.root_of >= 0, mb[:, 3], -1), n_ex_rows),
+                             index=self._index[0], index_bounds=self._index[1])
     if host_leaf:
         _ = self.asm, self.tab
     buf, wait = be.download_async(d_out, total_chars)
-
+    waits.append(wait)
     # the text of the host-expanded leaves: placed now (this engine's tables may belong to the next batch by the time the
     # caller collects the text), written into the buffer once the copy has landed
-    text_patches, host_index = [], []
+    text_patches, self._host_index = [], {}
     if host_leaf:
         A, msa = self.asm, self.tab["msa"]
         for lf, seqs in host_leaf.items():
-            if self.failed[msa[lf]]:
+            mi = int(msa[lf])
+            if self.failed[mi]:
                 continue
             pos, site = int(A[lf, A_START]), int(A[lf, A_SITE])
-            base = int(msa_base[msa[lf]])
+            base = int(msa_base[mi])
             many = len(seqs) > 1
             parts = [f" {site} "] if many else []
             at = pos + (len(parts[0]) if many else 0)
             for i, q in enumerate(seqs):
                 parts.append(q)
-                host_index.append((lf, at - base, at - base + len(q)))
+                self._host_index.setdefault(mi, []).append([at - base, at - base + len(q), int(A[lf, A_PRE])])
                 at += len(q)
                 if many:
                     parts.append(f" {site + 1 if i < len(seqs) - 1 else site} ")
                     at += len(parts[-1])
             text_patches.append((pos, "".join(parts).encode()))
-    if index_parts is not None:
-        jl, s0, s1 = index_parts
-        self.prg_index_arrays = (np.concatenate([jl, np.asarray([x[0] for x in host_index], np.int64)]),
-                                 np.concatenate([s0, np.asarray([x[1] for x in host_index], np.int64)]),
-                                 np.concatenate([s1, np.asarray([x[2] for x in host_index], np.int64)]))
     spans = list(zip(msa_base.tolist(), msa_len.tolist(), self.failed.tolist()))
 
     def finish():
-        """Wait for the copy; one bytes-like (or str) per alignment."""
-        wait()
+        """Wait for the copies; one bytes-like (or str) per alignment."""
+        for w_ in waits:
+            w_()
         for pos, txt in text_patches:
             buf[pos:pos + len(txt)] = np.frombuffer(txt, np.uint8)
         if as_bytes:          # zero-copy views into the batch buffer (ASCII); valid until the buffer's slot is reused
@@ -518,6 +551,8 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool =
         whole = buf.tobytes()
         return [None if bad else whole[a:a + ln].decode() for a, ln, bad in spans]
 
+    # (for callers that hand the text to native code: the pinned buffer and every alignment's span in it; valid after finish())
+    finish.buffer, finish.base, finish.length = buf, msa_base, np.where(self.failed, -1, msa_len)
     return finish if lazy else finish()
 
 
@@ -573,13 +608,99 @@ def forest_tree_dump(self: ForestEngine, mi: int, ids: List[str]) -> list:
     return out
 
 
+def forest_prg_index_entries(self: ForestEngine, mi: int) -> np.ndarray:
+    """[[start, end, node id], ...] of one alignment, device entries in preorder then those of host-expanded leaves
+    (assemble_prgs(want_index=True) first, and collect its text: the entries arrive with it)."""
+    ix, b = self._index
+    dev = ix[b[mi]:b[mi + 1]]
+    extra = self._host_index.get(mi)
+    return dev if not extra else np.concatenate([dev, np.asarray(extra, np.int32).reshape(-1, 3)])
+
+
 def forest_prg_index(self: ForestEngine, mi: int) -> list:
-    """[[start, end, node_id], ...] sorted, for one alignment (assemble_prgs(want_index=True) first)."""
-    leaf, s, e = self.prg_index_arrays
-    m = self.tab["msa"][leaf] == mi
-    node_id = self.node_id
-    return sorted([int(a), int(b), int(node_id[l])] for l, a, b in zip(leaf[m], s[m], e[m]))
+    """[[start, end, node_id], ...] sorted, for one alignment."""
+    return sorted(forest_prg_index_entries(self, mi).tolist())
 
 
+ForestEngine.prg_index_entries = forest_prg_index_entries
 ForestEngine.tree_dump = forest_tree_dump
 ForestEngine.prg_index = forest_prg_index
+
+
+# ======================================================================================================= batch ingest
+class _ArenaAlignment:
+    """One alignment of a raw arena (the native batch parser's output): what the engine reads of an MSA — its ASCII matrix."""
+    __slots__ = ("data", "pending_n")
+
+    def __init__(self, data):
+        self.data, self.pending_n = data, False
+
+
+class _ArenaBatch:
+    """The alignments of a raw arena as a sequence (len / index); matrices are views, made on demand."""
+
+    def __init__(self, arena: np.ndarray, raw_off: np.ndarray, rows: np.ndarray, cols: np.ndarray):
+        self.arena, self.raw_off, self.rows, self.cols = arena, raw_off, rows, cols
+
+    def __len__(self):
+        return len(self.rows)
+
+    def __getitem__(self, i):
+        i = int(i)
+        o, S, C = int(self.raw_off[i]), int(self.rows[i]), int(self.cols[i])
+        return _ArenaAlignment(self.arena[o:o + S * C].reshape(S, C))
+
+
+def load_raw(self: ForestEngine, arena_buf, arena: np.ndarray, raw_off: np.ndarray, rows: np.ndarray, cols: np.ndarray,
+             has_n: Optional[np.ndarray] = None, ids_of=None):
+    """Ingest of a batch the native parser laid out (mprg_ingest_fill_host): alignment i = rows[i] x cols[i] upper-cased ASCII
+    bytes at arena[raw_off[i]:]; arena_buf is the backend's (pinned) buffer behind `arena`.  The layout tables are built
+    array-at-a-time, the bytes go up in ONE copy from pinned memory, mprg_ingest codes and transposes on the device.
+    has_n: alignments that still hold N (their load-time consensus needs the device's column counts first).
+    ids_of(i): the row ids of alignment i (only asked for error messages and tree dumps)."""
+    be = self.be
+    M = len(rows)
+    rows, cols, raw_off = rows.astype(np.int64), cols.astype(np.int64), raw_off.astype(np.int64)
+    batch = _ArenaBatch(arena, raw_off, rows, cols)
+    self._msas, self._ids_of = batch, ids_of
+    self._ids = None
+    if has_n is not None and has_n.any():          # utils/seq_utils.py:246-290 on the device counts; patches the arena in place
+        todo = []
+        for i in np.nonzero(has_n)[0].tolist():
+            a = batch[i]
+            a.pending_n = True
+            todo.append(a)
+        self._resolve_pending_n(todo)
+    from .engine import _LazyCodes
+    self.codes = _LazyCodes(batch)
+    self.bad = {}
+    al = lambda x, a: (x + a - 1) // a * a
+    C0 = np.where(rows == 0, 0, cols)
+    pitchC, pitchS = al(np.maximum(C0, 1), 16), al(np.maximum(rows, 1), 16)
+    sz_rm, sz_cm = al(rows * pitchC, 256), al(C0 * pitchS, 256)
+    ends = np.cumsum(sz_rm + sz_cm)
+    rm = ends - sz_rm - sz_cm
+    cm = rm + sz_rm
+    tiles = ((rows + 63) // 64) * ((C0 + 63) // 64)
+    itab = np.zeros((max(M, 1), 9), np.int64)
+    itab[:M, 0], itab[:M, 1], itab[:M, 2], itab[:M, 3], itab[:M, 4] = raw_off, rows, C0, rm, cm
+    itab[:M, 5], itab[:M, 6], itab[:M, 7], itab[:M, 8] = pitchC, pitchS, -1, np.cumsum(tiles) - tiles
+    self.meta = np.stack([rm, cm, pitchC, pitchS, rows, C0], axis=1)
+    arena_bytes = int(ends[-1]) + 256 if M else 256
+    raw_bytes = int((raw_off + rows * cols).max()) if M else 0
+    self.d_arena = be.empty(arena_bytes)
+    d_raw = be.upload_from(arena_buf, raw_bytes)
+    d_itab, d_status = be.upload(itab), be.empty(4 * max(M, 1))
+    be.call("mprg_ingest", be.ptr(d_raw), be.ptr(d_itab), M, int(tiles.sum()), None, be.ptr(self.d_arena), arena_bytes,
+            be.ptr(d_status), be.stream, work=3.0 * float((rows * cols).sum()))
+    status = be.download(d_status, np.int32, M) if M else np.zeros(0, np.int32)
+    from .msa import encode
+    for i in np.nonzero(status)[0].tolist():          # utils/seq_utils.py:96-104: such a locus ends in SequenceCurationError
+        data = batch[i].data
+        r, c = np.argwhere(encode(data) == 255)[0]
+        rid = ids_of(i)[r] if ids_of is not None else f"row {r}"
+        self.bad[i] = SequenceCurationError(f"A slice of a sequence has a disallowed base ({chr(data[r, c])!r} in {rid}). Redo sequence curation.")
+    self.counters["arena_bytes"] = arena_bytes
+
+
+ForestEngine.load_raw = load_raw

@@ -85,6 +85,10 @@ class PrgBuilder(object):
 
     @staticmethod
     def deserialize_from_bytes(array_of_bytes: bytes) -> "PrgBuilder":
+        """A member of update_DS.zip: the packed form the batched driver writes (make_prg_amd/update_ds.py) or a pickle."""
+        from .update_ds import is_packed, unpack_member
+        if is_packed(array_of_bytes):
+            return unpack_member(array_of_bytes)
         return pickle.loads(array_of_bytes)
 
     @staticmethod

@@ -312,9 +312,10 @@ def materialise(eng: BatchEngine, res, alignment: MSA, prg_builder, parent_node=
 
 def materialise_forest(eng, mi: int, alignment: MSA, prg_builder, leaf_of: Optional[dict] = None) -> RecursiveTreeNode:
     """Same as materialise() for one tree of a forest.ForestEngine batch (assemble_prgs() must have run).
-    leaf_of (optional dict) receives {node table index: LeafNode} so that the caller can attach the batch's PRG index."""
+    leaf_of (optional dict) receives {node id: LeafNode} so that the caller can attach the batch's PRG index."""
     from .forest import KIND_INTERVAL, KIND_LEAF
     t = eng.tab
+    node_id = eng.node_id
     data = alignment.data
     pool = eng.pool_host() if eng.pool_used else np.zeros(0, np.int64)
 
@@ -325,7 +326,7 @@ def materialise_forest(eng, mi: int, alignment: MSA, prg_builder, leaf_of: Optio
         if kind == KIND_LEAF:
             leaf = LeafNode(level, stored, parent, prg_builder)
             if leaf_of is not None:
-                leaf_of[ni] = leaf
+                leaf_of[int(node_id[ni])] = leaf
             return leaf
         node = (MultiIntervalNode if kind == KIND_INTERVAL else MultiClusterNode)(level, stored, parent, prg_builder, [])
         for j in range(int(t["n_child"][ni])):

@@ -173,11 +173,6 @@ def _build_batch(msas, loci, options, backend, out: Dict[str, dict]):
         eng.load([msas[i] for i in uniq])
         eng.run_forest()
         prgs = eng.assemble_prgs(want_index=ot.prg)
-        if ot.prg:          # rows of the batch's PRG index grouped by alignment
-            ix_leaf, ix_s, ix_e = eng.prg_index_arrays
-            ix_msa = eng.tab["msa"][ix_leaf]
-            ix_order = np.argsort(ix_msa, kind="stable")
-            ix_bounds = np.searchsorted(ix_msa[ix_order], np.arange(len(uniq) + 1))
         for j, i in enumerate(uniq):
             if prgs[j] is None:
                 err = eng.errors[j]
@@ -195,9 +190,8 @@ def _build_batch(msas, loci, options, backend, out: Dict[str, dict]):
                 leaf_of = {}
                 builder = new_builder(loci[i], lambda b, j=j, i=i: materialise_forest(eng, j, msas[i], b, leaf_of))
                 builder.site_num = 5 + 2 * int(eng.site_count[j])
-                rows = ix_order[ix_bounds[j]:ix_bounds[j + 1]]
-                for ni, a, e in zip(ix_leaf[rows].tolist(), ix_s[rows].tolist(), ix_e[rows].tolist()):
-                    builder.update_PRG_index(a, e, leaf_of[ni])
+                for a, e, nid in eng.prg_index_entries(j).tolist():
+                    builder.update_PRG_index(a, e, leaf_of[nid])
                 if _CHECK_TREES:          # MPRG_CHECK=1: re-derive everything from the node objects (slow; tests do)
                     index, site = dict(builder.prg_index), builder.site_num
                     builder.clear_PRG_index()
@@ -341,7 +335,8 @@ def run(cl_options, backend=None):
     # unusable); with an explicit backend (tests) everything runs in-process.
     n_workers = max(1, int(getattr(options, "threads", 1) or 1)) if backend is None else 1
     pool = None
-    if n_workers > 1:
+    single_rank_pipeline = int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("MPRG_PIPELINE", "1") != "0"
+    if n_workers > 1 and not single_rank_pipeline:
         import multiprocessing as mp
         pool = mp.get_context("fork").Pool(n_workers)
     try:
@@ -363,6 +358,16 @@ def _run(options, backend, pool, n_workers):
     mine = shard_files(input_files, rank, world) if world > 1 else input_files
     import time
     t0 = time.time()
+    if dist is None and len(mine) > 1 and os.environ.get("MPRG_PIPELINE", "1") != "0":
+        # one GPU: the streamed file -> file pipeline (native batch parser and encoders with `-t` threads, chunks of
+        # alignments resident on the device, containers written while the next chunk builds); make_prg_amd/pipeline.py
+        from ..device import get_backend
+        from ..pipeline import run_pipeline
+        n_built = run_pipeline(mine, options, backend or get_backend())
+        logger.info(f"{n_built} of {len(mine)} loci built and written in {time.time() - t0:.1f}s ({max(1, int(getattr(options, 'threads', 1) or 1))} host threads)")
+        if n_built == 0:
+            logger.error("No PRGs were built, please check errors")
+        return
     if pool is not None and len(mine) >= 2 * n_workers:
         # several parts per worker, collected as they finish: the writer-side unpickling of one part overlaps the
         # building of the others (the per-locus outputs are ~0.5 MB each)

@@ -59,11 +59,18 @@ class EmuBackend(_Base):
         nbytes = int(count) * np.dtype(dtype).itemsize
         return buf[:nbytes].copy().view(dtype)
 
+    def pinned(self, nbytes, key):
+        a = np.zeros(max(int(nbytes), 16), np.uint8)
+        return a, a
+
+    def upload_from(self, pinned_buf, nbytes):
+        return pinned_buf[:int(nbytes)].copy() if nbytes else self.empty(16)
+
     def host_visible(self, nbytes):
         a = np.zeros(int(nbytes), np.uint8)
         return a, a
 
-    def download_async(self, buf, nbytes, slot=None):
+    def download_async(self, buf, nbytes, group=0):
         return buf[:int(nbytes)].copy(), (lambda: None)
 
     def ptr(self, buf):

@@ -119,3 +119,55 @@ def test_argument_parsing_and_logging_setup(tmp_path, golden_integration, monkey
     cli.main(["from_msa", "-i", str(d), "-o", str(tmp_path / "o1" / "x"), "-O", "p", "-N", "5", "-L", "7"])
     cli.main(["from_msa", "-i", str(d), "-o", str(tmp_path / "o2" / "x"), "-O", "p", "--log", str(tmp_path / "log.txt")])
     assert (tmp_path / "o1" / "x.prg.fa").read_text() == (tmp_path / "o2" / "x.prg.fa").read_text()
+
+
+def test_streamed_pipeline_equals_the_object_path(tmp_path, golden_integration, monkeypatch):
+    """The one-GPU file -> file pipeline (native batch parser / encoders, packed update_DS members, streamed zips; several
+    chunks) against the per-locus object path on the same directory: a gzipped file, a file with duplicate row ids, files with
+    N, a locus the curation policy skips — same .prg.fa bytes, same zip members, equal builders."""
+    import gzip
+    from make_prg_amd import device, pipeline
+    device.set_backend(EmuBackend())
+    d = tmp_path / "in"
+    d.mkdir()
+    n = 0
+    for case in golden_integration["cases"]:
+        if case["case"] in ("several", "match.nonmatch", "contains_n", "nested_snps_seq_backgrounds", "fails_2") and (case["N"], case["L"]) == (5, 7):
+            for l in case["loci"]:
+                name = f"{case['case']}_{l['file'].replace('.gz', '')}"
+                if n % 4 == 1:
+                    with gzip.open(d / (name + ".gz"), "wt") as fh:
+                        fh.write(l["fasta"])
+                else:
+                    (d / name).write_text(l["fasta"])
+                n += 1
+    (d / "dup_ids.fa").write_text(">a\nACGTACGTACGTTTTT\n>a\nACGTACGAACGTTTTT\n>b\nACGTACGTACGTATTT\n")
+    assert n >= 6
+    outs = {}
+    for mode, chunk in (("1", 3), ("0", 4096)):
+        monkeypatch.setenv("MPRG_PIPELINE", mode)
+        monkeypatch.setattr(pipeline, "CHUNK", chunk)
+        prefix = tmp_path / f"out{mode}" / "x"
+        o = options(d, prefix)
+        o.threads = 3
+        from_msa.run(o, backend=EmuBackend())
+        files = {p.name: p for p in (tmp_path / f"out{mode}").iterdir()}
+        assert sorted(files) == ["x.prg.bin.zip", "x.prg.fa", "x.prg.gfa.zip", "x.update_DS.zip"]
+        got = {"fa": files["x.prg.fa"].read_bytes()}
+        for kind in ("bin", "gfa"):
+            with zipfile.ZipFile(files[f"x.prg.{kind}.zip"]) as z:
+                assert z.testzip() is None
+                got[kind] = {m: z.read(m) for m in sorted(z.namelist())}
+        db = PrgBuilderZipDatabase(files["x.update_DS.zip"])
+        db.load()
+        got["builders"] = {l: db.get_PrgBuilder(l) for l in db.get_loci_names()}
+        db.close()
+        outs[mode] = got
+    a, b = outs["1"], outs["0"]
+    assert a["fa"] == b["fa"] and a["bin"] == b["bin"] and a["gfa"] == b["gfa"]
+    assert sorted(a["builders"]) == sorted(b["builders"]) and len(a["builders"]) >= 6
+    for l in a["builders"]:
+        x, y = a["builders"][l], b["builders"][l]
+        assert x == y, l
+        assert x.build_prg() == y.build_prg()
+        assert sorted((k, v.node_id) for k, v in x.prg_index.items()) == sorted((k, v.node_id) for k, v in y.prg_index.items())
