@@ -195,19 +195,20 @@ class HipBackend(_Base):
     def download_async(self, buf, nbytes: int, group: int = 0):
         """Start copying buf[:nbytes] into a PINNED host buffer on the backend's copy stream, behind everything enqueued on the
         compute stream so far; returns (uint8 array over the pinned buffer, wait()).  The array's contents are valid after
-        wait(); successive calls of one `group` alternate between two pinned buffers, so the copy of one batch overlaps the
-        kernels of the next and a result stays valid until the second following call of that group.
+        wait(); successive calls of one `group` cycle through `async_depth` (2) pinned buffers, so the copy of one batch overlaps
+        the kernels of the next and a result stays valid until the async_depth-th following call of that group.
         utils/io_utils.py:105-110 writes these bytes to files."""
         torch = self.torch
         nbytes = int(nbytes)
         if not hasattr(self, "_pinned"):
             self._pinned, self._copy_stream, self._parity = {}, torch.cuda.Stream(self.device), {}
-        par = self._parity.get(group, 0)
-        self._parity[group] = par ^ 1
+        depth = getattr(self, "async_depth", 2)          # buffers a group cycles through (a pipeline with three stages sets 3)
+        par = self._parity.get(group, 0) % depth
+        self._parity[group] = par + 1
         host = self._pinned.get((group, par))
         if host is None or host.numel() < nbytes:
-            # both buffers at once: page-locking GBs takes longer than a whole batch, better paid during warm-up
-            for q in (par, par ^ 1):
+            # all buffers at once: page-locking GBs takes longer than a whole batch, better paid during warm-up
+            for q in range(depth):
                 if self._pinned.get((group, q)) is None or self._pinned[(group, q)].numel() < nbytes:
                     self._pinned[(group, q)] = torch.empty(max(nbytes + (nbytes >> 3), 1 << 20), dtype=torch.uint8, pin_memory=True)
             host = self._pinned[(group, par)]

@@ -17,6 +17,7 @@ import logging
 import os
 import queue
 import threading
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import List
 
@@ -31,6 +32,14 @@ from .utils.zip_stream import StoredZipWriter
 
 logger = logging.getLogger("make_prg_amd")
 CHUNK = int(os.environ.get("MPRG_CHUNK", "4096"))          # alignment files per resident batch
+DEPTH = 3                                                  # chunks in flight: build | encode | write
+TRACE = os.environ.get("MPRG_PIPELINE_TRACE", "") not in ("", "0")
+
+
+def _trace(msg):
+    if TRACE:
+        import sys
+        sys.stderr.write("[pipeline] " + msg + "\n")
 
 
 def sort_key(path: Path) -> str:
@@ -54,17 +63,24 @@ class _Outputs:
             self.zips[kind] = StoredZipWriter(name, threads=max(2, min(8, self.threads)))
         return self.zips[kind]
 
-    def write_fa(self, pieces: List):
+    def plan_fa(self, pieces: List):
+        """Places the pieces at the end of <prefix>.prg.fa and returns the function that writes them there."""
         if self.fa_fd is None:
             self.fa_fd = os.open(self.prefix + ".prg.fa", os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-        for lo in range(0, len(pieces), 512):
-            chunk = pieces[lo:lo + 512]
-            want = sum(len(p) for p in chunk)
-            done = os.writev(self.fa_fd, chunk)
-            if done != want:                       # (short write: finish piece by piece)
-                flat = b"".join(bytes(p) for p in chunk)
-                while done < want:
-                    done += os.write(self.fa_fd, flat[done:])
+            self.fa_off = 0
+        at, fd = self.fa_off, self.fa_fd
+        self.fa_off += sum(len(p) for p in pieces)
+
+        def run():
+            off = at
+            for p in pieces:
+                mv = memoryview(p)
+                done = 0
+                while done < len(mv):
+                    done += os.pwrite(fd, mv[done:], off + done)
+                off += len(mv)
+
+        return run
 
     def close(self):
         if self.fa_fd is not None:
@@ -91,8 +107,10 @@ def _ingest(lib, paths: List[Path], threads: int):
     return h, info
 
 
-def run_pipeline(files: List[Path], options, be) -> int:
-    """Builds every locus of `files` and writes the run's output files.  Returns the number of loci built."""
+def run_pipeline(files: List[Path], options, backend) -> int:
+    """Builds every locus of `files` and writes the run's output files.  Returns the number of loci built.
+    backend: a backend object, or a function that makes one — it is called AFTER the ingest thread has started, so that reading
+    and parsing the first chunks overlaps importing torch and bringing up the device (~2 s of a command-line run)."""
     from .subcommands import from_msa as drv
     lib = native.library()
     if lib is None:
@@ -106,17 +124,21 @@ def run_pipeline(files: List[Path], options, be) -> int:
     q_in: "queue.Queue" = queue.Queue(maxsize=2)
     q_out: "queue.Queue" = queue.Queue()
     errors: List[BaseException] = []
-    # a chunk's pinned buffers (arena, PRG text, tree export: two of each, alternating) are read by the output stage until its
-    # members are written: the build of chunk i + 2 starts only when chunk i has left the output stage
-    in_flight = threading.Semaphore(2)
+    # a chunk's pinned buffers (arena, PRG text, tree export: DEPTH of each, used in turn) are read by the output stages until
+    # its members are written: the build of chunk i + DEPTH starts only when the writes of chunk i are done
+    in_flight = threading.Semaphore(DEPTH)
+    writers = ThreadPoolExecutor(4)
 
     def stage_ingest():
         try:
             for ci, chunk in enumerate(chunks):
                 if errors:
                     break
+                import time
+                t0 = time.perf_counter()
                 if fasta:
                     h, info = _ingest(lib, chunk, threads)
+                    _trace(f"chunk {ci}: read + scan {1e3 * (time.perf_counter() - t0):.0f} ms")
                 else:
                     h, info = None, np.full((len(chunk), 5), -3, np.int64)
                 q_in.put((ci, chunk, h, info))
@@ -130,8 +152,26 @@ def run_pipeline(files: List[Path], options, be) -> int:
                 item = q_out.get()
                 if item is None:
                     break
-                _write_chunk(lib, out, options, threads, *item)
-                in_flight.release()
+                jobs = _write_chunk(lib, out, options, threads, *item)
+                # the containers are written side by side while the next chunk is encoded; the chunk's buffers are free again
+                # once all of them are done
+                futs = [writers.submit(j) for j in jobs]
+                pending = [len(futs)]
+                lock = threading.Lock()
+
+                def done(f, pending=pending, lock=lock):
+                    if f.exception() is not None:
+                        errors.append(f.exception())
+                    with lock:
+                        pending[0] -= 1
+                        last = pending[0] == 0
+                    if last:
+                        in_flight.release()
+
+                if not futs:
+                    in_flight.release()
+                for f in futs:
+                    f.add_done_callback(done)
         except BaseException as err:
             errors.append(err)
             in_flight.release()
@@ -141,6 +181,8 @@ def run_pipeline(files: List[Path], options, be) -> int:
     t_in, t_out = threading.Thread(target=stage_ingest, daemon=True), threading.Thread(target=stage_output, daemon=True)
     t_in.start()
     t_out.start()
+    be = backend() if callable(backend) else backend
+    be.async_depth = DEPTH
     try:
         while True:
             item = q_in.get()
@@ -154,6 +196,7 @@ def run_pipeline(files: List[Path], options, be) -> int:
     finally:
         q_out.put(None)
         t_out.join()
+        writers.shutdown(wait=True)
     if errors:
         raise errors[0]
     out.close()
@@ -164,6 +207,8 @@ def _build_chunk(lib, be, options, threads, ci, chunk, h, info):
     """Device stage of one chunk: fast files through the arena, the rest through the object path.  Returns what the output
     stage needs."""
     from .subcommands import from_msa as drv
+    import time
+    t_start = time.perf_counter()
     ot = options.output_type
     status, rows, cols, tbytes, flags = (info[:, k] for k in range(5))
     for i in np.nonzero((status == -7) | (status == -6))[0].tolist():
@@ -181,7 +226,7 @@ def _build_chunk(lib, be, options, threads, ci, chunk, h, info):
         sizes = rows[fi] * cols[fi]
         raw_off = np.cumsum(sizes) - sizes
         t_off = np.cumsum(tbytes[fi]) - tbytes[fi]
-        arena_buf, arena = be.pinned(int(sizes.sum()), ("arena", ci & 1))
+        arena_buf, arena = be.pinned(int(sizes.sum()), ("arena", ci % DEPTH))
         titles = np.empty(max(int(tbytes[fi].sum()), 1), np.uint8)
         ro_all, to_all = np.full(len(chunk), -1, np.int64), np.zeros(len(chunk), np.int64)
         ro_all[fi], to_all[fi] = raw_off, t_off
@@ -191,10 +236,14 @@ def _build_chunk(lib, be, options, threads, ci, chunk, h, info):
             t = titles[t_off[j]:t_off[j] + tbytes[fi[j]]].tobytes().decode("ascii").split("\n")[:-1]
             return [(x.split(None, 1) or [""])[0] for x in t]
 
+        t_fill = time.perf_counter()
         eng = ForestEngine(be, options.max_nesting, options.min_match_length)
         eng.load_raw(arena_buf, arena, raw_off, rows[fi], cols[fi], has_n=(flags[fi] & 2) != 0, ids_of=ids_of)
         eng.run_forest()
+        t_load = time.perf_counter()
         fin = eng.assemble_prgs(as_bytes=True, lazy=True, export=ot.prg)
+        _trace(f"chunk {ci}: fill {1e3 * (t_fill - t_start):.0f} ms, load + forest {1e3 * (t_load - t_fill):.0f} ms, "
+               f"assemble {1e3 * (time.perf_counter() - t_load):.0f} ms ({len(fi)} alignments)")
         res.update(eng=eng, fin=fin, arena=arena, raw_off=raw_off, rows=rows[fi], cols=cols[fi], titles=titles, t_off=t_off,
                    tbytes=tbytes[fi], site_count=None)
     if slow:          # gzip / non-ASCII / duplicate ids / other formats: the object path, inside this chunk
@@ -216,12 +265,15 @@ def _build_chunk(lib, be, options, threads, ci, chunk, h, info):
 
 def _write_chunk(lib, out: _Outputs, options, threads, res):
     """Output stage of one chunk: encoders + CRCs by native threads, members streamed into the containers."""
+    import time
+    tw0 = time.perf_counter()
     ot = options.output_type
     chunk, fi = res["chunk"], res["fi"]
     names = [remove_known_input_extensions(p.name) for p in chunk]
     n_fast = len(fi)
     fast_pos = {int(i): j for j, i in enumerate(fi.tolist())}
     prgs = []
+    buf0_ok = False
     if n_fast:
         eng = res["eng"]
         prgs = res["fin"]()                           # waits for the chunk's copies; memoryviews into the pinned text buffer
@@ -231,9 +283,11 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
                 if not isinstance(err, SequenceCurationError):
                     raise err
                 logger.warning(f"Skipping building PRG for {names[int(fi[j])]}. Error: {err}")
+        tw1 = time.perf_counter()
         fin = res["fin"]
         whole = np.frombuffer(fin.buffer, np.uint8) if len(fin.buffer) else np.zeros(1, np.uint8)
         base, length = np.ascontiguousarray(fin.base, np.int64), np.ascontiguousarray(fin.length, np.int64)
+        buf0_ok = True
         if True:
             bin_words, gfa_bytes = np.zeros(n_fast, np.int64), np.zeros(n_fast, np.int64)
             lib.mprg_encode_sizes_host(whole.ctypes.data, base.ctypes.data, length.ctypes.data, n_fast, threads, int(ot.binary),
@@ -246,10 +300,17 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
             lib.mprg_encode_fill_host(whole.ctypes.data, base.ctypes.data, length.ctypes.data, n_fast, threads,
                                       bin_buf.ctypes.data if ot.binary else None, bin_off.ctypes.data, bin_words.ctypes.data,
                                       gfa_buf.ctypes.data if ot.gfa else None, gfa_off.ctypes.data, gfa_bytes.ctypes.data, crc.ctypes.data)
+    tw2 = time.perf_counter()
     # ---- members in the chunk's (sorted) locus order; the rare loci of the object path and those the one-pass encoders do not
     #      cover come as bytes
     fa, zb, zg, zp = [], ([], [], [], []), ([], [], [], []), ([], [], [], [])
     pk_jobs = []
+    # (plain Python ints and one memoryview per big buffer: NumPy scalars and array slices would dominate this loop)
+    if n_fast and buf0_ok:
+        bw_l, bo_l, gb_l, go_l = bin_words.tolist(), bin_off.tolist(), gfa_bytes.tolist(), gfa_off.tolist()
+        crc_l = crc.tolist()
+        bin_mv = memoryview(bin_buf).cast("B") if ot.binary else None
+        gfa_mv = memoryview(gfa_buf) if ot.gfa else None
     for i, locus in enumerate(names):
         j = fast_pos.get(i)
         if j is None:
@@ -258,7 +319,7 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
                 continue
             out.n += 1
             text = rec["prg"].encode()
-            fa += [f">{locus}\n".encode(), text, b"\n"]
+            fa += [(">" + locus + "\n").encode(), text, b"\n"]
             for kind, dst in (("bin", zb), ("gfa", zg), ("pickle", zp)):
                 if kind in rec:
                     import zlib
@@ -272,58 +333,75 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
             continue
         out.n += 1
         if ot.prg:
-            fa += [f">{locus}\n".encode(), p, b"\n"]
+            fa += [(">" + locus + "\n").encode(), p, b"\n"]
         if ot.binary:
-            if bin_words[j] >= 0:
-                piece = memoryview(bin_buf[bin_off[j]:bin_off[j] + bin_words[j]]).cast("B")
-                c = int(crc[j, 1])
+            if bw_l[j] >= 0:
+                piece = bin_mv[4 * bo_l[j]:4 * (bo_l[j] + bw_l[j])]
+                c = crc_l[j][1]
             else:          # the reference-shaped encoder owns this string (and its errors)
                 from .utils.prg_encoder import PrgEncoder
                 import zlib
                 piece = np.asarray(PrgEncoder().encode(bytes(p).decode()), "<u4").tobytes()
                 c = zlib.crc32(piece)
-            zb[0].append(f"{locus}.bin"); zb[1].append([piece]); zb[2].append(c); zb[3].append(len(piece))
+            zb[0].append(locus + ".bin"); zb[1].append([piece]); zb[2].append(c); zb[3].append(len(piece))
         if ot.gfa:
-            if gfa_bytes[j] >= 0:
-                piece = memoryview(gfa_buf[gfa_off[j]:gfa_off[j] + gfa_bytes[j]])
-                c = int(crc[j, 2])
+            if gb_l[j] >= 0:
+                piece = gfa_mv[go_l[j]:go_l[j] + gb_l[j]]
+                c = crc_l[j][2]
             else:
                 from .utils.gfa import GFA_Output
                 import zlib
                 piece = GFA_Output.gfa_bytes(bytes(p).decode())
                 c = zlib.crc32(piece)
-            zg[0].append(f"{locus}.gfa"); zg[1].append([piece]); zg[2].append(c); zg[3].append(len(piece))
+            zg[0].append(locus + ".gfa"); zg[1].append([piece]); zg[2].append(c); zg[3].append(len(piece))
         if ot.prg:
             pk_jobs.append((locus, j))
     if pk_jobs:          # update_DS members: header + slices of the arena, the titles and the device's tree export
         eng, ex = res["eng"], res["eng"].exported
-        site_count = eng.site_count
-        arena, raw_off, rows, cols, titles, t_off, tbytes = (res[k] for k in ("arena", "raw_off", "rows", "cols", "titles", "t_off", "tbytes"))
-        nb, rb, ib = ex["node_bounds"], ex["row_bounds"], ex["index_bounds"]
+        site_l = eng.site_count.tolist()
+        arena, titles = res["arena"], res["titles"]
+        ro_l, S_l, C_l, to_l, tb_l = (res[k].tolist() for k in ("raw_off", "rows", "cols", "t_off", "tbytes"))
+        nb, rb, ib = ex["node_bounds"].tolist(), ex["row_bounds"].tolist(), ex["index_bounds"].tolist()
         recs_b = memoryview(ex["records"]).cast("B")
         rows_b = memoryview(ex["rows"]).cast("B") if len(ex["rows"]) else memoryview(b"")
         index_b = memoryview(ex["index"]).cast("B") if len(ex["index"]) else memoryview(b"")
         arena_b, titles_b = memoryview(arena), memoryview(titles)
-        seg_ptr, seg_len = [], []
+        fmt, N_, L_ = options.alignment_format, options.max_nesting, options.min_match_length
         for locus, j in pk_jobs:
-            n_nodes, n_rows, n_ix = int(nb[j + 1] - nb[j]), int(rb[j + 1] - rb[j]), int(ib[j + 1] - ib[j])
+            n_nodes, n_rows, n_ix = nb[j + 1] - nb[j], rb[j + 1] - rb[j], ib[j + 1] - ib[j]
             extra = eng._host_index.get(j)
-            S, C = int(rows[j]), int(cols[j])
+            S, C = S_l[j], C_l[j]
             ix_extra = np.asarray(extra, np.int32).tobytes() if extra else b""
-            head = member_header(locus, options.alignment_format, options.max_nesting, options.min_match_length, n_nodes,
-                                 5 + 2 * int(site_count[j]), S, C, int(tbytes[j]), n_nodes, n_rows, n_ix + len(ix_extra) // 12)
-            pieces = [head, arena_b[raw_off[j]:raw_off[j] + S * C], titles_b[t_off[j]:t_off[j] + tbytes[j]],
+            head = member_header(locus, fmt, N_, L_, n_nodes, 5 + 2 * site_l[j], S, C, tb_l[j], n_nodes, n_rows, n_ix + len(ix_extra) // 12)
+            pieces = [head, arena_b[ro_l[j]:ro_l[j] + S * C], titles_b[to_l[j]:to_l[j] + tb_l[j]],
                       recs_b[32 * nb[j]:32 * nb[j + 1]], rows_b[4 * rb[j]:4 * rb[j + 1]], index_b[12 * ib[j]:12 * ib[j + 1]]]
+            size = len(head) + S * C + tb_l[j] + 32 * n_nodes + 4 * n_rows + 12 * n_ix
             if ix_extra:
                 pieces.append(ix_extra)
-            zp[0].append(locus); zp[1].append(pieces); zp[3].append(sum(len(x) for x in pieces))
+                size += len(ix_extra)
+            zp[0].append(locus); zp[1].append(pieces); zp[3].append(size)
     if zp[0]:            # CRC-32 of the update_DS members by the native threads: one running value over a member's pieces
         zp[2][:] = _crc_members(lib, zp[1], threads)
+    tw3 = time.perf_counter()
+    _trace(f"chunk {res['ci']}: wait for text {1e3 * ((tw1 if n_fast else tw0) - tw0):.0f} ms, encode {1e3 * (tw2 - (tw1 if n_fast else tw0)):.0f} ms, "
+           f"members {1e3 * (tw3 - tw2):.0f} ms")
+    jobs = []
+    keep = res                      # the chunk's buffers stay referenced by the jobs until they have run
+
+    def timed(name, fn):
+        def run(keep=keep):
+            t0 = time.perf_counter()
+            fn()
+            _trace(f"chunk {res['ci']}: wrote {name} in {1e3 * (time.perf_counter() - t0):.0f} ms")
+        return run
+
+    # places are taken here, in chunk order; the copies run later, side by side with those of the neighbouring chunks
     if fa and ot.prg:
-        out.write_fa(fa)
+        jobs.append(timed("prg.fa", out.plan_fa(fa)))
     for kind, dst, want in (("bin", zb, ot.binary), ("gfa", zg, ot.gfa), ("pickle", zp, ot.prg)):
         if want and dst[0]:
-            out.zip(kind).add_many(*dst)
+            jobs.append(timed(kind, out.zip(kind).plan_many(*dst)))
+    return jobs
 
 
 def _crc_members(lib, members: List[List], threads: int) -> List[int]:

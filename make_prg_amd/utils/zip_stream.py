@@ -31,8 +31,10 @@ class StoredZipWriter:
     def _local_header(name: bytes, crc: int, size: int) -> bytes:
         return struct.pack("<IHHHHHIIIHH", _LOCAL, 20, 0, 0, 0, _DOSDATE, crc & 0xFFFFFFFF, size, size, len(name), 0) + name
 
-    def add_many(self, names: Sequence[str], buffers: Sequence[List], crcs: Sequence[int], sizes: Sequence[int]):
-        """Append members; buffers[i] = the list of bytes-like pieces of member i (their total length is sizes[i] < 4 GiB)."""
+    def plan_many(self, names: Sequence[str], buffers: Sequence[List], crcs: Sequence[int], sizes: Sequence[int]):
+        """Places members (the cheap, ordered part: offsets, directory entries) and returns the function that writes them —
+        callers may run the writers of successive batches concurrently: the places are disjoint.
+        buffers[i] = the list of bytes-like pieces of member i (their total length is sizes[i] < 4 GiB)."""
         self._open()
         jobs = []
         for name, bufs, crc, size in zip(names, buffers, crcs, sizes):
@@ -41,21 +43,29 @@ class StoredZipWriter:
             jobs.append((self.offset, [head] + list(bufs)))
             self.entries.append((nb, int(crc) & 0xFFFFFFFF, int(size), self.offset))
             self.offset += len(head) + int(size)
-        if not jobs:
-            return
-        n_part = min(len(jobs), self.pool._max_workers * 4)
-        step = (len(jobs) + n_part - 1) // n_part
+        fd = self.fd
 
-        def write(lo):
-            for off, pieces in jobs[lo:lo + step]:
-                for p in pieces:                      # (os.pwritev would need the pieces' total under 2 GiB and IOV_MAX)
-                    mv = memoryview(p)
-                    done = 0
-                    while done < len(mv):
-                        done += os.pwrite(self.fd, mv[done:], off + done)
-                    off += len(mv)
+        def run():
+            if not jobs:
+                return
+            n_part = min(len(jobs), self.pool._max_workers * 4)
+            step = (len(jobs) + n_part - 1) // n_part
 
-        list(self.pool.map(write, range(0, len(jobs), step)))
+            def write(lo):
+                for off, pieces in jobs[lo:lo + step]:
+                    for p in pieces:                      # (os.pwritev would need the pieces' total under 2 GiB and IOV_MAX)
+                        mv = memoryview(p)
+                        done = 0
+                        while done < len(mv):
+                            done += os.pwrite(fd, mv[done:], off + done)
+                        off += len(mv)
+
+            list(self.pool.map(write, range(0, len(jobs), step)))
+
+        return run
+
+    def add_many(self, names, buffers, crcs, sizes):
+        self.plan_many(names, buffers, crcs, sizes)()
 
     def add(self, name: str, data: bytes, crc: int = None):
         import zlib

@@ -32,4 +32,5 @@ if __name__ == "__main__":
                                   "-t", t, "-O", ot, "--log", os.path.join(tmp, "log.txt")], cwd=root, capture_output=True, text=True)
             dt = time.time() - t0
             print(f"-O {ot} -t {t}: {n} files in {dt:.1f}s = {n / dt:.0f} loci/s (rc {res.returncode}) {res.stderr[-300:] if res.returncode else ''}", flush=True)
+            print("".join(l for l in res.stderr.splitlines(True) if l.startswith("[pipeline]")), end="")
             print("   " + " | ".join(l.split(":", 2)[-1].strip() for l in open(os.path.join(tmp, "log.txt")) if "built in" in l or "written in" in l)[-300:])
