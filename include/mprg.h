@@ -391,6 +391,9 @@ void mprg_encode_sizes_host(const char *prg, const long long *base, const long l
 void mprg_encode_fill_host(const char *prg, const long long *base, const long long *len, long long n, int n_threads,
                            uint32_t *bin_out, const long long *bin_off, const long long *bin_words, char *gfa_out,
                            const long long *gfa_off, const long long *gfa_bytes, uint32_t *crc);
+/* scatter-gather output: piece k = len[k] bytes at address addr[k] -> file offset file_off[k] of fd, n_threads threads; 0 or -1 */
+int mprg_write_pieces_host(int fd, const long long *addr, const long long *len, const long long *file_off, long long n_pieces,
+                           int n_threads);
 /* CRC-32 of zip members given as pieces (member i = pieces first[i] .. first[i+1]-1; piece k = len[k] bytes at address addr[k]) */
 void mprg_crc32_members_host(const long long *addr, const long long *len, const long long *first, long long n_members, int n_threads,
                              uint32_t *crc);

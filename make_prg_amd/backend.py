@@ -74,6 +74,7 @@ SIGNATURES = {
     "mprg_encode_sizes_host": (None, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mprg_encode_fill_host": (None, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int] + [c_void_p] * 7),
     "mprg_crc32_members_host": (None, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p]),
+    "mprg_write_pieces_host": (c_int, [c_int, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int]),
 }
 
 

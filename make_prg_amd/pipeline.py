@@ -63,22 +63,19 @@ class _Outputs:
             self.zips[kind] = StoredZipWriter(name, threads=max(2, min(8, self.threads)))
         return self.zips[kind]
 
-    def plan_fa(self, pieces: List):
-        """Places the pieces at the end of <prefix>.prg.fa and returns the function that writes them there."""
+    def plan_fa(self, addr, ln, lib, threads: int):
+        """Places pieces (address table) at the end of <prefix>.prg.fa and returns the function that writes them there."""
         if self.fa_fd is None:
             self.fa_fd = os.open(self.prefix + ".prg.fa", os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
             self.fa_off = 0
-        at, fd = self.fa_off, self.fa_fd
-        self.fa_off += sum(len(p) for p in pieces)
+        addr, ln = np.ascontiguousarray(addr, np.int64), np.ascontiguousarray(ln, np.int64)
+        off = self.fa_off + np.cumsum(ln) - ln
+        self.fa_off += int(ln.sum())
+        fd = self.fa_fd
 
         def run():
-            off = at
-            for p in pieces:
-                mv = memoryview(p)
-                done = 0
-                while done < len(mv):
-                    done += os.pwrite(fd, mv[done:], off + done)
-                off += len(mv)
+            if len(ln) and lib.mprg_write_pieces_host(fd, addr.ctypes.data, ln.ctypes.data, off.ctypes.data, len(ln), threads) != 0:
+                raise OSError(f"writing {self.prefix}.prg.fa failed")
 
         return run
 
@@ -127,7 +124,7 @@ def run_pipeline(files: List[Path], options, backend) -> int:
     # a chunk's pinned buffers (arena, PRG text, tree export: DEPTH of each, used in turn) are read by the output stages until
     # its members are written: the build of chunk i + DEPTH starts only when the writes of chunk i are done
     in_flight = threading.Semaphore(DEPTH)
-    writers = ThreadPoolExecutor(4)
+    writers = ThreadPoolExecutor(int(os.environ.get("MPRG_WRITERS", "4")))
 
     def stage_ingest():
         try:
@@ -263,130 +260,77 @@ def _build_chunk(lib, be, options, threads, ci, chunk, h, info):
     return (res,)
 
 
+def _addr(a) -> int:
+    return np.frombuffer(a, np.uint8).ctypes.data if len(a) else 0
+
+
 def _write_chunk(lib, out: _Outputs, options, threads, res):
-    """Output stage of one chunk: encoders + CRCs by native threads, members streamed into the containers."""
+    """Output stage of one chunk: encoders + CRCs by native threads; the containers' members as ADDRESS TABLES over the chunk's
+    buffers (array arithmetic for the loci of the arena path, a few Python bytes for the rare others).  Returns the write jobs
+    (places already taken, in chunk order)."""
     import time
+    import zlib
     tw0 = time.perf_counter()
     ot = options.output_type
     chunk, fi = res["chunk"], res["fi"]
+    n_chunk, n_fast = len(chunk), len(fi)
     names = [remove_known_input_extensions(p.name) for p in chunk]
-    n_fast = len(fi)
-    fast_pos = {int(i): j for j, i in enumerate(fi.tolist())}
-    prgs = []
-    buf0_ok = False
+    keep = [res]                       # everything the tables point into
+    # per locus of the chunk (in its sorted order): where its PRG text lies; -1 = no PRG
+    t_addr, t_len = np.zeros(n_chunk, np.int64), np.full(n_chunk, -1, np.int64)
+    tw1 = tw0
     if n_fast:
-        eng = res["eng"]
-        prgs = res["fin"]()                           # waits for the chunk's copies; memoryviews into the pinned text buffer
-        for j in range(n_fast):
-            if prgs[j] is None:
-                err = eng.errors[j]
-                if not isinstance(err, SequenceCurationError):
-                    raise err
-                logger.warning(f"Skipping building PRG for {names[int(fi[j])]}. Error: {err}")
+        eng, fin = res["eng"], res["fin"]
+        prgs = fin()                                  # waits for the chunk's copies (text, tree export)
         tw1 = time.perf_counter()
-        fin = res["fin"]
+        length = np.ascontiguousarray(fin.length, np.int64)
+        base = np.ascontiguousarray(fin.base, np.int64)
+        for j in np.nonzero(length < 0)[0].tolist():
+            err = eng.errors[j]
+            if not isinstance(err, SequenceCurationError):
+                raise err
+            logger.warning(f"Skipping building PRG for {names[int(fi[j])]}. Error: {err}")
         whole = np.frombuffer(fin.buffer, np.uint8) if len(fin.buffer) else np.zeros(1, np.uint8)
-        base, length = np.ascontiguousarray(fin.base, np.int64), np.ascontiguousarray(fin.length, np.int64)
-        buf0_ok = True
-        if True:
-            bin_words, gfa_bytes = np.zeros(n_fast, np.int64), np.zeros(n_fast, np.int64)
-            lib.mprg_encode_sizes_host(whole.ctypes.data, base.ctypes.data, length.ctypes.data, n_fast, threads, int(ot.binary),
-                                       int(ot.gfa), bin_words.ctypes.data, gfa_bytes.ctypes.data)
-            bw, gb = np.maximum(bin_words, 0), np.maximum(gfa_bytes, 0)
-            bin_off, gfa_off = np.cumsum(bw) - bw, np.cumsum(gb) - gb
-            bin_buf = np.empty(max(int(bw.sum()), 1), np.uint32) if ot.binary else None
-            gfa_buf = np.empty(max(int(gb.sum()), 1), np.uint8) if ot.gfa else None
-            crc = np.zeros((n_fast, 3), np.uint32)
-            lib.mprg_encode_fill_host(whole.ctypes.data, base.ctypes.data, length.ctypes.data, n_fast, threads,
-                                      bin_buf.ctypes.data if ot.binary else None, bin_off.ctypes.data, bin_words.ctypes.data,
-                                      gfa_buf.ctypes.data if ot.gfa else None, gfa_off.ctypes.data, gfa_bytes.ctypes.data, crc.ctypes.data)
+        keep.append(whole)
+        bin_words, gfa_bytes = np.zeros(n_fast, np.int64), np.zeros(n_fast, np.int64)
+        lib.mprg_encode_sizes_host(whole.ctypes.data, base.ctypes.data, length.ctypes.data, n_fast, threads, int(ot.binary),
+                                   int(ot.gfa), bin_words.ctypes.data, gfa_bytes.ctypes.data)
+        bw, gb = np.maximum(bin_words, 0), np.maximum(gfa_bytes, 0)
+        bin_off, gfa_off = np.cumsum(bw) - bw, np.cumsum(gb) - gb
+        bin_buf = np.empty(max(int(bw.sum()), 1), np.uint32) if ot.binary else None
+        gfa_buf = np.empty(max(int(gb.sum()), 1), np.uint8) if ot.gfa else None
+        keep += [bin_buf, gfa_buf]
+        crc = np.zeros((n_fast, 3), np.uint32)
+        lib.mprg_encode_fill_host(whole.ctypes.data, base.ctypes.data, length.ctypes.data, n_fast, threads,
+                                  bin_buf.ctypes.data if ot.binary else None, bin_off.ctypes.data, bin_words.ctypes.data,
+                                  gfa_buf.ctypes.data if ot.gfa else None, gfa_off.ctypes.data, gfa_bytes.ctypes.data, crc.ctypes.data)
+        t_addr[fi], t_len[fi] = whole.ctypes.data + base, length
     tw2 = time.perf_counter()
-    # ---- members in the chunk's (sorted) locus order; the rare loci of the object path and those the one-pass encoders do not
-    #      cover come as bytes
-    fa, zb, zg, zp = [], ([], [], [], []), ([], [], [], []), ([], [], [], [])
-    pk_jobs = []
-    # (plain Python ints and one memoryview per big buffer: NumPy scalars and array slices would dominate this loop)
-    if n_fast and buf0_ok:
-        bw_l, bo_l, gb_l, go_l = bin_words.tolist(), bin_off.tolist(), gfa_bytes.tolist(), gfa_off.tolist()
-        crc_l = crc.tolist()
-        bin_mv = memoryview(bin_buf).cast("B") if ot.binary else None
-        gfa_mv = memoryview(gfa_buf) if ot.gfa else None
-    for i, locus in enumerate(names):
-        j = fast_pos.get(i)
-        if j is None:
-            rec = res["slow_records"].get(locus)
-            if rec is None:
-                continue
-            out.n += 1
-            text = rec["prg"].encode()
-            fa += [(">" + locus + "\n").encode(), text, b"\n"]
-            for kind, dst in (("bin", zb), ("gfa", zg), ("pickle", zp)):
-                if kind in rec:
-                    import zlib
-                    dst[0].append(locus if kind == "pickle" else f"{locus}.{kind}")
-                    dst[1].append([rec[kind]]); dst[3].append(len(rec[kind]))
-                    if kind != "pickle":          # (the update_DS members' CRCs are computed together below)
-                        dst[2].append(zlib.crc32(rec[kind]))
+    # ---- the loci of the object path and the PRGs the one-pass encoders do not cover: bytes, one by one (rare)
+    extra = {"bin": [], "gfa": [], "pickle": []}          # (member name, bytes)
+    fast_set = set(fi.tolist()) if n_fast < n_chunk else None
+    for i in ([i for i in range(n_chunk) if i not in fast_set] if fast_set is not None else ()):
+        rec = res["slow_records"].get(names[i])
+        if rec is None:
             continue
-        p = prgs[j]
-        if p is None:
-            continue
-        out.n += 1
-        if ot.prg:
-            fa += [(">" + locus + "\n").encode(), p, b"\n"]
-        if ot.binary:
-            if bw_l[j] >= 0:
-                piece = bin_mv[4 * bo_l[j]:4 * (bo_l[j] + bw_l[j])]
-                c = crc_l[j][1]
-            else:          # the reference-shaped encoder owns this string (and its errors)
-                from .utils.prg_encoder import PrgEncoder
-                import zlib
-                piece = np.asarray(PrgEncoder().encode(bytes(p).decode()), "<u4").tobytes()
-                c = zlib.crc32(piece)
-            zb[0].append(locus + ".bin"); zb[1].append([piece]); zb[2].append(c); zb[3].append(len(piece))
-        if ot.gfa:
-            if gb_l[j] >= 0:
-                piece = gfa_mv[go_l[j]:go_l[j] + gb_l[j]]
-                c = crc_l[j][2]
-            else:
-                from .utils.gfa import GFA_Output
-                import zlib
-                piece = GFA_Output.gfa_bytes(bytes(p).decode())
-                c = zlib.crc32(piece)
-            zg[0].append(locus + ".gfa"); zg[1].append([piece]); zg[2].append(c); zg[3].append(len(piece))
-        if ot.prg:
-            pk_jobs.append((locus, j))
-    if pk_jobs:          # update_DS members: header + slices of the arena, the titles and the device's tree export
-        eng, ex = res["eng"], res["eng"].exported
-        site_l = eng.site_count.tolist()
-        arena, titles = res["arena"], res["titles"]
-        ro_l, S_l, C_l, to_l, tb_l = (res[k].tolist() for k in ("raw_off", "rows", "cols", "t_off", "tbytes"))
-        nb, rb, ib = ex["node_bounds"].tolist(), ex["row_bounds"].tolist(), ex["index_bounds"].tolist()
-        recs_b = memoryview(ex["records"]).cast("B")
-        rows_b = memoryview(ex["rows"]).cast("B") if len(ex["rows"]) else memoryview(b"")
-        index_b = memoryview(ex["index"]).cast("B") if len(ex["index"]) else memoryview(b"")
-        arena_b, titles_b = memoryview(arena), memoryview(titles)
-        fmt, N_, L_ = options.alignment_format, options.max_nesting, options.min_match_length
-        for locus, j in pk_jobs:
-            n_nodes, n_rows, n_ix = nb[j + 1] - nb[j], rb[j + 1] - rb[j], ib[j + 1] - ib[j]
-            extra = eng._host_index.get(j)
-            S, C = S_l[j], C_l[j]
-            ix_extra = np.asarray(extra, np.int32).tobytes() if extra else b""
-            head = member_header(locus, fmt, N_, L_, n_nodes, 5 + 2 * site_l[j], S, C, tb_l[j], n_nodes, n_rows, n_ix + len(ix_extra) // 12)
-            pieces = [head, arena_b[ro_l[j]:ro_l[j] + S * C], titles_b[to_l[j]:to_l[j] + tb_l[j]],
-                      recs_b[32 * nb[j]:32 * nb[j + 1]], rows_b[4 * rb[j]:4 * rb[j + 1]], index_b[12 * ib[j]:12 * ib[j + 1]]]
-            size = len(head) + S * C + tb_l[j] + 32 * n_nodes + 4 * n_rows + 12 * n_ix
-            if ix_extra:
-                pieces.append(ix_extra)
-                size += len(ix_extra)
-            zp[0].append(locus); zp[1].append(pieces); zp[3].append(size)
-    if zp[0]:            # CRC-32 of the update_DS members by the native threads: one running value over a member's pieces
-        zp[2][:] = _crc_members(lib, zp[1], threads)
-    tw3 = time.perf_counter()
-    _trace(f"chunk {res['ci']}: wait for text {1e3 * ((tw1 if n_fast else tw0) - tw0):.0f} ms, encode {1e3 * (tw2 - (tw1 if n_fast else tw0)):.0f} ms, "
-           f"members {1e3 * (tw3 - tw2):.0f} ms")
+        text = rec["prg"].encode()
+        keep.append(text)
+        t_addr[i], t_len[i] = _addr(text), len(text)
+        for kind in extra:
+            if kind in rec:
+                extra[kind].append((names[i] if kind == "pickle" else f"{names[i]}.{kind}", rec[kind]))
+    ok = np.zeros(0, bool)
+    if n_fast:
+        ok = length >= 0
+        for j in np.nonzero(ok & (bin_words < 0) & bool(ot.binary))[0].tolist():      # the reference-shaped encoders own these strings
+            from .utils.prg_encoder import PrgEncoder
+            extra["bin"].append((names[int(fi[j])] + ".bin", np.asarray(PrgEncoder().encode(bytes(prgs[j]).decode()), "<u4").tobytes()))
+        for j in np.nonzero(ok & (gfa_bytes < 0) & bool(ot.gfa))[0].tolist():
+            from .utils.gfa import GFA_Output
+            extra["gfa"].append((names[int(fi[j])] + ".gfa", GFA_Output.gfa_bytes(bytes(prgs[j]).decode())))
+    built = np.nonzero(t_len >= 0)[0]
+    out.n += len(built)
     jobs = []
-    keep = res                      # the chunk's buffers stay referenced by the jobs until they have run
 
     def timed(name, fn):
         def run(keep=keep):
@@ -395,30 +339,77 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
             _trace(f"chunk {res['ci']}: wrote {name} in {1e3 * (time.perf_counter() - t0):.0f} ms")
         return run
 
-    # places are taken here, in chunk order; the copies run later, side by side with those of the neighbouring chunks
-    if fa and ot.prg:
-        jobs.append(timed("prg.fa", out.plan_fa(fa)))
-    for kind, dst, want in (("bin", zb, ot.binary), ("gfa", zg, ot.gfa), ("pickle", zp, ot.prg)):
-        if want and dst[0]:
-            jobs.append(timed(kind, out.zip(kind).plan_many(*dst)))
+    def zip_job(kind, member_names, addr, ln, crcs):
+        for nm, data in extra[kind]:          # the rare bytes members ride along: one more row each
+            keep.append(data)
+            row_a, row_l = np.zeros((1, addr.shape[1]), np.int64), np.zeros((1, addr.shape[1]), np.int64)
+            row_a[0, 0], row_l[0, 0] = _addr(data), len(data)
+            addr, ln = np.concatenate([addr, row_a]), np.concatenate([ln, row_l])
+            member_names = member_names + [nm]
+            crcs = np.concatenate([crcs, [zlib.crc32(data)]])
+        if len(member_names):
+            jobs.append(timed(kind, out.zip(kind).plan_table(member_names, addr, ln, crcs, lib, max(2, min(8, threads)), keep)))
+
+    # ---- <prefix>.prg.fa: ">locus\n" PRG "\n" per built locus, in order
+    if ot.prg and len(built):
+        heads = [(">" + names[i] + "\n").encode() for i in built.tolist()]
+        blob = np.frombuffer(b"".join(heads) + b"\n", np.uint8)
+        hl = np.fromiter((len(h) for h in heads), np.int64, len(heads))
+        addr = np.empty((len(built), 3), np.int64)
+        ln = np.empty_like(addr)
+        addr[:, 0], ln[:, 0] = blob.ctypes.data + np.cumsum(hl) - hl, hl
+        addr[:, 1], ln[:, 1] = t_addr[built], t_len[built]
+        addr[:, 2], ln[:, 2] = blob.ctypes.data + blob.size - 1, 1
+        keep.append(blob)
+        jobs.append(timed("prg.fa", out.plan_fa(addr.reshape(-1), ln.reshape(-1), lib, max(2, min(8, threads)))))
+    # ---- zip members of the arena path's loci
+    okj = np.nonzero(ok)[0]
+    ok_names = [names[i] for i in fi[okj].tolist()] if n_fast else []
+    if ot.binary:
+        sel = okj[bin_words[okj] >= 0] if n_fast else okj
+        zip_job("bin", [names[i] + ".bin" for i in fi[sel].tolist()] if n_fast else [],
+                (bin_buf.ctypes.data + 4 * bin_off[sel]).reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64),
+                (4 * bin_words[sel]).reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64), crc[sel, 1] if n_fast else np.zeros(0, np.uint32))
+    if ot.gfa:
+        sel = okj[gfa_bytes[okj] >= 0] if n_fast else okj
+        zip_job("gfa", [names[i] + ".gfa" for i in fi[sel].tolist()] if n_fast else [],
+                (gfa_buf.ctypes.data + gfa_off[sel]).reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64),
+                gfa_bytes[sel].reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64), crc[sel, 2] if n_fast else np.zeros(0, np.uint32))
+    if ot.prg:          # update_DS members: header + slices of the arena, the titles and the device's tree export
+        K = 7
+        n_m = len(okj)
+        addr, ln = np.zeros((n_m, K), np.int64), np.zeros((n_m, K), np.int64)
+        crcs = np.zeros(n_m, np.uint32)
+        if n_m:
+            ex = eng.exported
+            site = eng.site_count[okj]
+            S, C, ro, to, tb = (res[k][okj] for k in ("rows", "cols", "raw_off", "t_off", "tbytes"))
+            nb, rb, ib = ex["node_bounds"], ex["row_bounds"], ex["index_bounds"]
+            n_nodes, n_rows, n_ix = nb[okj + 1] - nb[okj], rb[okj + 1] - rb[okj], ib[okj + 1] - ib[okj]
+            extra_ix = [np.asarray(eng._host_index[j], np.int32).tobytes() if j in eng._host_index else b"" for j in okj.tolist()] \
+                if eng._host_index else None
+            fmt, N_, L_ = options.alignment_format, options.max_nesting, options.min_match_length
+            heads = [member_header(nm, fmt, N_, L_, a, 5 + 2 * b, c, d, e, a, f, g + (len(extra_ix[q]) // 12 if extra_ix else 0))
+                     for q, (nm, a, b, c, d, e, f, g) in enumerate(zip(ok_names, n_nodes.tolist(), site.tolist(), S.tolist(), C.tolist(),
+                                                                        tb.tolist(), n_rows.tolist(), n_ix.tolist()))]
+            blob = np.frombuffer(b"".join(heads), np.uint8)
+            hl = np.fromiter((len(h) for h in heads), np.int64, n_m)
+            keep += [blob, res["titles"]]
+            addr[:, 0], ln[:, 0] = blob.ctypes.data + np.cumsum(hl) - hl, hl
+            addr[:, 1], ln[:, 1] = res["arena"].ctypes.data + ro, S * C
+            addr[:, 2], ln[:, 2] = res["titles"].ctypes.data + to, tb
+            addr[:, 3], ln[:, 3] = ex["records"].ctypes.data + 32 * nb[okj], 32 * n_nodes
+            addr[:, 4], ln[:, 4] = ex["rows"].ctypes.data + 4 * rb[okj], 4 * n_rows
+            addr[:, 5], ln[:, 5] = ex["index"].ctypes.data + 12 * ib[okj], 12 * n_ix
+            if extra_ix:
+                for q, b_ in enumerate(extra_ix):
+                    if b_:
+                        keep.append(b_)
+                        addr[q, 6], ln[q, 6] = _addr(b_), len(b_)
+            first = np.arange(n_m + 1, dtype=np.int64) * K
+            a_flat, l_flat = np.ascontiguousarray(addr.reshape(-1)), np.ascontiguousarray(ln.reshape(-1))
+            lib.mprg_crc32_members_host(a_flat.ctypes.data, l_flat.ctypes.data, first.ctypes.data, n_m, threads, crcs.ctypes.data)
+        zip_job("pickle", ok_names, addr, ln, crcs)
+    _trace(f"chunk {res['ci']}: wait for copies {1e3 * (tw1 - tw0):.0f} ms, encode {1e3 * (tw2 - tw1):.0f} ms, "
+           f"tables + places {1e3 * (time.perf_counter() - tw2):.0f} ms")
     return jobs
-
-
-def _crc_members(lib, members: List[List], threads: int) -> List[int]:
-    """CRC-32 of members given as lists of pieces, by the native threads (one running value per member)."""
-    n = sum(len(pieces) for pieces in members)
-    addr, ln, first = np.empty(n, np.int64), np.empty(n, np.int64), np.zeros(len(members) + 1, np.int64)
-    keep, k = [], 0
-    for i, pieces in enumerate(members):
-        for p in pieces:
-            if len(p):
-                a = np.frombuffer(p, np.uint8)
-                keep.append(a)
-                addr[k], ln[k] = a.ctypes.data, a.size
-            else:
-                addr[k], ln[k] = 0, 0
-            k += 1
-        first[i + 1] = k
-    crc = np.zeros(len(members), np.uint32)
-    lib.mprg_crc32_members_host(addr.ctypes.data, ln.ctypes.data, first.ctypes.data, len(members), threads, crc.ctypes.data)
-    return [int(c) for c in crc]

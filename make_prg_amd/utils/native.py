@@ -25,6 +25,7 @@ HOST_SIGNATURES = {
     "mprg_encode_sizes_host": (None, [_P, _P, _P, _LL, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "mprg_encode_fill_host": (None, [_P, _P, _P, _LL, ctypes.c_int] + [_P] * 7),
     "mprg_crc32_members_host": (None, [_P, _P, _P, _LL, ctypes.c_int, _P]),
+    "mprg_write_pieces_host": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _LL, ctypes.c_int]),
 }
 _lib = None
 _tried = False

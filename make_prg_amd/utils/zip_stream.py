@@ -67,6 +67,40 @@ class StoredZipWriter:
     def add_many(self, names, buffers, crcs, sizes):
         self.plan_many(names, buffers, crcs, sizes)()
 
+    def plan_table(self, names: Sequence[str], data_addr, data_len, crcs, lib, threads: int, keep=None):
+        """plan_many for members given as ADDRESS TABLES (int64 [members, pieces]: where each piece of a member's data lies in
+        memory and how long it is) — the batch's members are slices of a few big buffers, so the tables are array arithmetic and
+        the copies one call of libmprg's scatter-gather writer (mprg_write_pieces_host, `threads` native threads, no GIL).
+        keep: whatever must stay alive until the returned function has run."""
+        import numpy as np
+        self._open()
+        n = len(names)
+        data_addr = np.ascontiguousarray(data_addr, np.int64).reshape(n, -1)
+        data_len = np.ascontiguousarray(data_len, np.int64).reshape(n, -1)
+        sizes = data_len.sum(axis=1)
+        heads = [self._local_header(nm.encode("utf-8"), int(c), int(sz)) for nm, c, sz in zip(names, np.asarray(crcs).tolist(), sizes.tolist())]
+        blob = np.frombuffer(b"".join(heads), np.uint8) if n else np.zeros(0, np.uint8)
+        hl = np.fromiter((len(h) for h in heads), np.int64, n)
+        addr = np.empty((n, data_addr.shape[1] + 1), np.int64)
+        ln = np.empty_like(addr)
+        addr[:, 0] = blob.ctypes.data + np.cumsum(hl) - hl
+        ln[:, 0] = hl
+        addr[:, 1:], ln[:, 1:] = data_addr, data_len
+        flat_len = ln.reshape(-1)
+        off = self.offset + np.cumsum(flat_len) - flat_len
+        starts = off.reshape(n, -1)[:, 0].tolist() if n else []
+        for nm, c, sz, st in zip(names, np.asarray(crcs).tolist(), sizes.tolist(), starts):
+            self.entries.append((nm.encode("utf-8"), int(c) & 0xFFFFFFFF, int(sz), int(st)))
+        self.offset += int(flat_len.sum())
+        fd = self.fd
+        addr, off = np.ascontiguousarray(addr.reshape(-1)), np.ascontiguousarray(off)
+
+        def run(keep=(keep, blob)):
+            if n and lib.mprg_write_pieces_host(fd, addr.ctypes.data, flat_len.ctypes.data, off.ctypes.data, len(flat_len), threads) != 0:
+                raise OSError(f"writing {self.path} failed")
+
+        return run
+
     def add(self, name: str, data: bytes, crc: int = None):
         import zlib
         self.add_many([name], [[data]], [zlib.crc32(data) if crc is None else crc], [len(data)])
