@@ -129,7 +129,7 @@ def source_digest():
     return h.hexdigest()[:16]
 
 
-def _worker(conn, device, seeds, n_streams, gen_procs=1):
+def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None):
     """One host worker process: owns `n_streams` engines (HIP streams, one host thread each) on GPU `device` and a share
     of the rank's alignments.  The reference's own parallelism is a process pool over MSAs (from_msa `-t`); here the
     processes feed one GPU so that the array-at-a-time host control of several sub-batches overlaps."""
@@ -139,6 +139,10 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1):
         from make_prg_amd.backend import HipBackend
         from make_prg_amd.forest import ForestEngine
         texts, msas = make_batch(seeds, gen_procs)      # forks (if at all) before this process touches the GPU
+        if cli_dir:                                     # the command-line leg reads the same alignments as FASTA files
+            for sd, t in zip(seeds, texts):
+                with open(os.path.join(cli_dir, f"gene{sd:05d}.fa"), "w") as fh:
+                    fh.write(t)
         n_streams = max(1, min(n_streams, len(msas)))
         bes = [HipBackend(device, own_stream=True) for _ in range(n_streams)]
         engs = [ForestEngine(b, max_nesting=5, min_match_length=7) for b in bes]
@@ -280,6 +284,8 @@ def main():
                          "sharded over the ranks unless --weak")
     ap.add_argument("--weak", action="store_true", help="every rank builds all --batch alignments (weak scaling)")
     ap.add_argument("--no-single-worker-leg", action="store_true")
+    ap.add_argument("--no-cli-leg", action="store_true", help="skip the file -> file run of the command line (N=1 only)")
+    ap.add_argument("--cli-threads", type=int, default=0, help="-t of the command-line leg (0 = the CPUs this process may use, at most 16)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
@@ -336,10 +342,16 @@ def main():
         W = max(1, min(W, max(1, (ncpu - 1) // max(world, 1)), int(avail_kib / (4 << 20) / 4 / max(world, 1))))
     gen_procs = args.gen_procs or max(1, min(16, ncpu // (max(W, 1) * max(world, 1))))
     parts = lpt_parts(seeds, W) if W > 1 else [seeds]
+    cli_dir = None
+    if world == 1 and not args.no_cli_leg and W >= 1:
+        import tempfile
+        cli_root = tempfile.mkdtemp(prefix="mprg_bench_cli_")
+        cli_dir = os.path.join(cli_root, "msas")
+        os.mkdir(cli_dir)
     conns, procs, th = [], [], None
     for w in range(W):
         a, b = ctx.Pipe()
-        pr = ctx.Process(target=_worker, args=(b, local_rank, parts[w], args.streams, gen_procs))
+        pr = ctx.Process(target=_worker, args=(b, local_rank, parts[w], args.streams, gen_procs, cli_dir))
         pr.start()
         conns.append(a); procs.append(pr)
     if W == 0:          # --workers 0: the same worker loop on a thread of this process (rocprofv3 runs: nothing forks)
@@ -459,7 +471,7 @@ def main():
     if rank == 0 and world == 1 and W > 1 and not args.no_single_worker_leg:
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--workers", "1", "--steps", str(max(3, args.steps // 2)), "--warmup", "2",
-               "--batch", str(args.batch), "--no-cpu-baseline", "--no-end-to-end", "--no-single-worker-leg"]
+               "--batch", str(args.batch), "--no-cpu-baseline", "--no-end-to-end", "--no-single-worker-leg", "--no-cli-leg"]
         try:
             line = subprocess.run(cmd, capture_output=True, text=True, timeout=900, check=True).stdout.strip().splitlines()[-1]
             one = json.loads(line)
@@ -468,6 +480,48 @@ def main():
                           exclusive_pass=one["roofline"]["exclusive_pass"], verified_mismatches=one["config"]["verified"]["mismatches"])
         except Exception as err:          # reported, not hidden
             single = dict(error=f"{type(err).__name__}: {err}"[:300])
+
+    # ---- the command line, file -> file: the same alignments as FASTA files on local disk -> .prg.fa, .prg.bin.zip, .prg.gfa.zip,
+    #      update_DS.zip (-O a); a fresh process, so the rate includes interpreter + device start-up
+    cli = None
+    if cli_dir is not None and rank == 0:
+        import hashlib as _hl
+        import shutil
+        import subprocess
+        t_cli = args.cli_threads or max(1, min(16, ncpu))
+        outp = os.path.join(cli_root, "out", "pan")
+        logp = os.path.join(cli_root, "log.txt")
+        cmd = [sys.executable, "-m", "make_prg_amd", "from_msa", "-i", cli_dir, "-o", outp, "-t", str(t_cli), "-O", "a", "--log", logp]
+        try:
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1800)
+            dt_cli = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr[-400:])
+            sizes = {n_: os.path.getsize(os.path.join(cli_root, "out", n_)) for n_ in sorted(os.listdir(os.path.join(cli_root, "out")))}
+            # a sample of the written PRGs against the oracle's digests
+            bad_cli = checked = 0
+            if os.path.exists(DIGESTS):
+                from tests.config_c_full import load_digests
+                blob = load_digests(DIGESTS)
+                with open(outp + ".prg.fa", "rb") as fh:
+                    for k, line in enumerate(fh):
+                        if k % 2 == 0:
+                            name = line[1:-1].decode()
+                        elif (k // 2) % 10 == 0:
+                            sd = int(name[4:])
+                            if sd * 12 + 12 <= len(blob):
+                                checked += 1
+                                bad_cli += _hl.sha256(line[:-1]).digest()[:8] != blob[12 * sd:12 * sd + 8]
+            pipe_s = next((float(l.split(" in ")[1].split("s")[0]) for l in open(logp) if "built and written" in l), None)
+            cli = dict(value=round(len(seeds) / dt_cli, 3), unit="MSAs/s", seconds=round(dt_cli, 3), files=len(seeds), threads=t_cli,
+                       output_types="a (.prg.fa, .prg.bin.zip, .prg.gfa.zip, update_DS.zip)", pipeline_seconds=pipe_s,
+                       region="python -m make_prg_amd from_msa: FASTA files on local disk -> every output file (a fresh process: "
+                              "interpreter, torch import and device start-up included; pipeline_seconds = after the input list is read)",
+                       output_bytes=sizes, prgs_checked_against_digests=checked, mismatches=int(bad_cli))
+        except Exception as err:          # reported, not hidden
+            cli = dict(error=f"{type(err).__name__}: {err}"[:400])
+        shutil.rmtree(cli_root, ignore_errors=True)
 
     # whole-job counters (strong scaling: a rank's workers only saw its shard)
     keys = ("launches", "fits", "cells_all", "cells_clustered", "kmeans_bytes", "syncs")
@@ -527,7 +581,7 @@ def main():
                                    "SURVEY.md §8d generator, seeds 0..batch-1), -N 5 -L 7; one step = every alignment of the job, "
                                    "resident, sharded over the ranks by size (--weak: all of them on every rank)",
                        "alignments_per_step": msas_per_step, "alignments_rank0": len(seeds), "parallelism": f"shard{world}",
-                       "host_worker_processes_per_gpu": W, "cpus_rank0": ncpu, "single_worker": single,
+                       "host_worker_processes_per_gpu": W, "cpus_rank0": ncpu, "single_worker": single, "cli": cli,
                        "streams_per_worker": args.streams, "event_timing_in_timed_region": bool(args.profile_timed),
                        "step_includes": "recursion forest (kernels + device-side bookkeeping; the host sizes buffers from one header per "
                                         "step) + PRG text laid out and written on the device + its copy to pinned host memory",

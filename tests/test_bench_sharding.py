@@ -28,7 +28,7 @@ def test_two_ranks_share_one_job_strong_scaling():
     env = dict(os.environ, MPRG_DIST_BACKEND="gloo", MPRG_DEVICE_MODULO="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "600", "--steps", "2", "--warmup", "1",
-           "--workers", "1", "--no-cpu-baseline", "--no-end-to-end"]
+           "--workers", "1", "--no-cpu-baseline", "--no-end-to-end", "--no-cli-leg"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
