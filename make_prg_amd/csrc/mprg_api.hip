@@ -119,7 +119,7 @@ int mprg_kmer_dictionary(const int64_t *views, const int64_t *prob, int n_probs,
                          uint8_t *table, uint8_t *first_flag, int32_t *out_V, void *stream) {
   (void)ulen;
   if (n_probs <= 0) return 0;
-  if (kmer_size < 1 || kmer_size > 16) return fail("k-mer size must be in 1..16 (4-bit packed keys)");
+  if (kmer_size < 1) return fail("k-mer size must be positive");
   LAUNCH(k_kmer_dictionary, n_probs, KD_THREADS, stream, views, prob, kmer_size, ucodes, seqrow, (const int64_t *)occ_off, table,
          first_flag, out_V);
   return check_launch("k_kmer_dictionary");
@@ -130,7 +130,7 @@ int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int
                      double *xcounts, void *stream) {
   (void)ulen;
   if (n_probs <= 0) return 0;
-  if (kmer_size < 1 || kmer_size > 16) return fail("k-mer size must be in 1..16 (4-bit packed keys)");
+  if (kmer_size < 1) return fail("k-mer size must be positive");
   LAUNCH(k_kmer_counts, n_probs, 512, stream, views, prob, kmer_size, ucodes, seqrow, occ_off, table, xcounts);
   return check_launch("k_kmer_counts");
 }

@@ -554,6 +554,10 @@ class BatchEngine:
         be.call("mprg_kmer_dictionary", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(d_ucodes), be.ptr(d_ulen),
                 be.ptr(d_seqrow), be.ptr(d_occ), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), be.stream)
         V = be.download(d_V, np.int32, P).astype(np.int64)
+        if ((V >> 24) == 0x7f).any():
+            raise MprgError("k-mer dictionary: no hash seed separated the k-mers of a clustering problem (k-mer size > 16)")
+        ptab[:, 5] |= (V >> 24) << 40               # k > 16: the hash seed that held rides in the capacity field (mprg_kmer_counts)
+        V &= 0xFFFFFF
         xo = wo = lo = 0
         for i, p in enumerate(probs):
             p["V"] = int(V[i])

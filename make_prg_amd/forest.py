@@ -251,6 +251,8 @@ class ForestEngine(BatchEngine):
         # ---- S5: count matrices, workspaces, launch classes, biggest fits first
         self._scratch(P)
         h = self._step("sizes_count", n_hdr=21)
+        if h[14]:
+            raise MprgError("k-mer dictionary: no hash seed separated the k-mers of a clustering problem (k-mer size > 16)")
         if h[15]:
             raise MprgError("a k-mer count matrix has more than 4 194 304 features: beyond the KMeans kernels' pairwise-sum stack")
         x_doubles, ws_doubles, n_wc, n_wr = int(h[0]), int(h[1]), int(h[7]), int(h[8])
