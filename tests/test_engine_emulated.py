@@ -53,3 +53,8 @@ def test_load_time_consensus_counts_from_the_device(emu):
     BatchEngine(emu, 5, 7).load(got)
     for w, g in zip(want, got):
         assert not g.pending_n and np.array_equal(w.data, g.data)
+
+
+def test_kmer_sizes_above_16(emu):
+    from tests.long_kmer_common import check_long_kmers
+    assert check_long_kmers(emu) == 4

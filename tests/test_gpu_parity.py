@@ -55,6 +55,12 @@ def test_kmeans_known_answers_persistent_workgroups(hip, golden_kmeans):
             assert g["n_iter"] == f["n_iter"]
 
 
+def test_kmer_sizes_above_16(hip):
+    """-L 17 / 20 / 24 / 33: the real reference's answers (verified hash keys in the k-mer dictionary)."""
+    from tests.long_kmer_common import check_long_kmers
+    assert check_long_kmers(hip) == 4
+
+
 def test_batch_of_fresh_seeds_against_oracle(hip):
     from make_prg_amd.utils.synthetic import synth_config_fasta
     texts = [synth_config_fasta("B", s) for s in range(100, 148)]
