@@ -254,7 +254,8 @@ int mprg_emit_alleles(const uint8_t *arena, const int64_t *jobs, int64_t n_jobs,
  * node table: MPRG_NODE_FIELDS int64 per node; the nodes of a recursion level are one contiguous range, the children of a node
  * are contiguous inside the next level's range.
  * F (every entry point's first argument): a HOST array of MPRG_F_FIELDS int64 — device addresses and sizes, read at call time.
- * MPRG_F_VALS: int64 [items][MPRG_FOREST_VALS_COLS] scratch of the step; MPRG_F_SCAN_TMP: int64 [items / 2048 + 2][same];
+ * MPRG_F_VALS: int64 [MPRG_FOREST_VALS_COLS][items] scratch of the step (column-major); MPRG_F_SCAN_TMP: int64 [items / 2048 + 2]
+ * [MPRG_FOREST_VALS_COLS];
  * MPRG_F_HDR: int64 [MPRG_FOREST_HDR] of device memory that receives the step's totals (column sums, see each step). */
 enum {
   MPRG_N_MSA = 0, MPRG_N_PARENT = 1, MPRG_N_LEVEL = 2 /* nesting level */, MPRG_N_ROWS_OFF = 3 /* row pool offset, -1: all rows */,
@@ -288,7 +289,7 @@ enum {
   /* assembly */
   MPRG_F_ASM = 54, MPRG_F_ROOT_OF = 55, MPRG_F_SPECIAL_LIST = 56, MPRG_F_SPECIAL_CAP = 57, MPRG_F_PATCH = 58, MPRG_F_N_PATCH = 59,
   MPRG_F_LEVELS = 60 /* HOST int64 [levels][4]: first node, nodes, reps_pos, reps_len (device addresses or 0) */, MPRG_F_N_LEVELS = 61,
-  MPRG_F_VALS_MSA = 62 /* int64 [alignments][cols]: col 0 becomes tree base, then text base */, MPRG_F_VALS_NODE = 63,
+  MPRG_F_VALS_MSA = 62 /* int64 [alignments]: every alignment's first place in the preorder layouts */, MPRG_F_VALS_NODE = 63,
   MPRG_F_VALS_POS = 64, MPRG_F_N_SITES = 65, MPRG_F_JOBS = 66, MPRG_F_OUT = 67, MPRG_F_MSA_BASE = 68, MPRG_F_UOFF = 69 /* .. 79: offset of k's uniforms, k = 2..10 */,
   MPRG_F_FIT_LISTS = 81 /* int32 [7][P]: the round's fits per launch list (hdr 86-92) */,
   MPRG_F_INDEX_OUT = 83 /* optional int32 [jobs][3]: the PRG index {start, end, node id}, per locus contiguous */,

@@ -466,7 +466,7 @@ int mprg_forest_export_fill(const int64_t *F, void *stream) {
   if (n <= 0) return 0;
   LAUNCH(k_ex_fill, KF_GRID(n), 256, stream, FP(const int64_t, MPRG_F_NODES), n, FP(const int64_t, MPRG_F_ASM), FP(const int64_t, MPRG_F_VALS_MSA),
          FP(const int64_t, MPRG_F_VALS_POS), FP(const int32_t, MPRG_F_POOL), FP(int32_t, MPRG_F_EX_RECORDS), FP(int32_t, MPRG_F_EX_ROWS),
-         FP(int64_t, MPRG_F_MSA_BASE));
+         FP(int64_t, MPRG_F_MSA_BASE), (long long)F[MPRG_F_N_MSAS]);
   return check_launch("k_ex_fill");
 }
 #undef FP

@@ -123,12 +123,15 @@ class ForestEngine(BatchEngine):
         roots[:, N_ACHARS], roots[:, N_AUX] = meta[ok, 5], -1
         self.F = np.zeros(F_FIELDS, np.int64)
         self._alive: Dict[str, object] = {}
-        self.n_nodes, self.cap_nodes = len(ok), max(4 * len(ok), 1024)
+        # capacity: what the previous forest of this engine needed (a resident batch is rebuilt step after step), else a guess
+        # of 64 nodes per alignment; growing means a device-to-device copy of the table
+        self.n_nodes = len(ok)
+        self.cap_nodes = max(getattr(self, "_nodes_hint", 0), 64 * len(ok), 1024)
         self.d_nodes = be.empty(8 * NODE_FIELDS * self.cap_nodes)
         if len(ok):
             self.d_nodes = be.grown(be.upload(roots), roots.nbytes, 8 * NODE_FIELDS * self.cap_nodes)
-        self.pool_cap, self.pool_used = 0, 0
-        self.d_pool = be.empty(16)
+        self.pool_cap, self.pool_used = 4 * getattr(self, "_pool_hint", 0), 0
+        self.d_pool = be.empty(max(self.pool_cap, 16))
         self.d_hdr = be.zeros(8 * HDR)
         if not hasattr(self, "_hdr_buf"):
             self._hdr_buf, raw = be.host_visible(8 * HDR)
@@ -150,6 +153,7 @@ class ForestEngine(BatchEngine):
             self.counters["levels"] += 1
             f0, n = self._forest_level(f0, n)
             self._alive = {k: v for k, v in self._alive.items() if k in ("NODES", "META", "FAILED", "ERR_FIRST", "POOL", "ARENA", "HDR", "HDR_HOST")}
+        self._nodes_hint, self._pool_hint = self.n_nodes + (self.n_nodes >> 4), self.pool_used + (self.pool_used >> 4)
         # per-locus policy: the locus is dropped, the batch goes on; the first failing view in frontier order names the error
         if M and len(ok):
             failed_dev = be.download(self.d_failed, np.int32, M) != 0
@@ -458,8 +462,8 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool =
             self.d_failed = be.upload(self.failed.astype(np.int32))
             self._set(FAILED=self.d_failed)
     d_asm = be.empty(8 * ASM_FIELDS * n)
-    d_vm, d_vn, d_vp = be.empty(8 * VC * M), be.empty(8 * VC * n), be.empty(8 * VC * n)
-    d_nsites, d_mbase = be.empty(8 * M), be.empty(8 * VC * M)
+    d_vm, d_vn, d_vp = be.empty(8 * M), be.empty(8 * n), be.empty(8 * n)          # one-column tables
+    d_nsites, d_mbase = be.empty(8 * M), be.empty(8 * 4 * M)
     self._set(ASM=d_asm, PATCH=d_patch, N_PATCH=n_patch, N_LEVELS=len(self.levels), VALS_MSA=d_vm, VALS_NODE=d_vn, VALS_POS=d_vp,
               N_SITES=d_nsites, MSA_BASE=d_mbase, SCAN_TMP=be.empty(8 * VC * (max(n, M) // 2048 + 2)))
     self.F[FI["LEVELS"]] = lv_arr.ctypes.data
@@ -483,7 +487,7 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool =
     # small copies before the big asynchronous one (a copy queued behind 2.5 GB on the DMA engine waits for it).
     # per alignment: start of its PRG in the batch text, first allele job / index entry, first node of its preorder run,
     # first entry of its exported rows
-    mb = be.download(d_mbase, np.int64, VC * M).reshape(M, VC)
+    mb = be.download(d_mbase, np.int64, 4 * M).reshape(4, M).T          # (column-major on the device)
     msa_base = mb[:, 0].copy()
     msa_len = np.diff(np.concatenate([msa_base, [total_chars]]))
 

@@ -4,7 +4,7 @@
 #   2. rocprofv3 --kernel-trace --stats of bench.py in its in-process mode (--workers 0: nothing forks under the profiler,
 #      one stream: kernel durations are exclusive)
 #   3. + 4. HBM traffic: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM section)
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -13,7 +13,7 @@ lscpu | grep -E "Model name|^CPU\(s\)|Thread|Core|Socket" >> $out/host.txt
 cat $out/host.txt
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 echo "bench rc=$?"
-inproc="--workers 0 --streams 1 --batch 8192 --no-cpu-baseline --no-end-to-end --steps 2"   # one process generates its alignments serially: smaller batch
+inproc="--workers 0 --streams 1 --batch 8192 --no-cpu-baseline --no-end-to-end --no-cli-leg --no-single-worker-leg --steps 2"   # one process generates its alignments serially: smaller batch
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py $inproc > $out/bench_under_rocprof.json 2> $out/prof.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py $inproc > $out/pmc_fetch_bench.json 2> $out/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py $inproc > $out/pmc_write_bench.json 2> $out/pmc_write.err
