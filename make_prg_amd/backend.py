@@ -96,20 +96,37 @@ class _Base:
     profile = None   # set to a dict to collect per-entry-point device time (HIP events on the launch stream)
     profile_only = None   # optional set of entry points to time (None: all of them)
 
-    def call(self, name, *args, work: float = 0.0):
-        """Enqueue one C-ABI entry point.  `work` = algorithmic bytes of this launch (roofline accounting)."""
+    def call(self, name, *args, work: float = 0.0, side: Optional[int] = None):
+        """Enqueue one C-ABI entry point.  `work` = algorithmic bytes of this launch (roofline accounting).  side: the launch
+        goes to side stream `side` (its stream argument must be side_ptr(side)): the timing events are recorded there."""
         ev = self._event_pair() if self.profile is not None and (self.profile_only is None or name in self.profile_only) else None
         if ev:
-            ev[0].record()
+            self._record(ev[0], side)
         rc = getattr(self.lib, name)(*args)
         if ev:
-            ev[1].record()
+            self._record(ev[1], side)
             self.profile.setdefault(name, []).append((ev[0], ev[1], float(work)))
         if rc != 0:
             raise MprgError(f"{name} failed ({rc}): {self.lib.mprg_last_error().decode()}")
 
     def _event_pair(self):
         return None
+
+    def _record(self, event, side):
+        event.record()
+
+    # side streams: independent launches of one step side by side (fork: they wait for what the main stream holds so far;
+    # join: the main stream waits for them).  The base class has none: everything stays on the one stream.
+    n_side_streams = 0
+
+    def side_ptr(self, i: int):
+        return self.stream
+
+    def fork(self, n: int):
+        pass
+
+    def join(self, n: int):
+        pass
 
     def profile_summary(self):
         """{entry point: dict(calls, ms, bytes)} from the recorded events (synchronises)."""
@@ -236,5 +253,32 @@ class HipBackend(_Base):
         self.stream_obj.synchronize()
 
     def _event_pair(self):
-        # torch.cuda.Event wraps hipEvent_t; kernels are enqueued on torch's current stream, the one these record on
+        # torch.cuda.Event wraps hipEvent_t; kernels are enqueued on the backend's stream, the one these record on
         return (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))
+
+    def _record(self, event, side):
+        event.record(self.stream_obj if side is None else self._side[side])
+
+    n_side_streams = 3
+
+    def _sides(self, n):
+        if not hasattr(self, "_side"):
+            self._side = []
+        while len(self._side) < n:
+            self._side.append(self.torch.cuda.Stream(self.device))
+        return self._side[:n]
+
+    def side_ptr(self, i: int):
+        return self._sides(i + 1)[i].cuda_stream
+
+    def fork(self, n: int):
+        ev = self.torch.cuda.Event()
+        ev.record(self.stream_obj)
+        for s_ in self._sides(n):
+            s_.wait_event(ev)
+
+    def join(self, n: int):
+        for s_ in self._sides(n):
+            ev = self.torch.cuda.Event()
+            ev.record(s_)
+            self.stream_obj.wait_event(ev)

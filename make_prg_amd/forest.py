@@ -46,6 +46,7 @@ KM_LISTS = (("mprg_kmeans_fit_wave", 0), ("mprg_kmeans_fit_wave", 1), ("mprg_kme
             ("mprg_kmeans_fit", None), ("mprg_kmeans_fit_small", 0), ("mprg_kmeans_fit_small", 1))
 # which forms small fits take: bit 0 wave form (measured slower on MI355X: profiles/r03/kmeans_forms.md), bit 1 small workgroups
 KM_MODE = int(os.environ.get("MPRG_KM_MODE", "2"))
+XX
 F_FIELDS = 96
 PREPARE_CLASSES = 4                      # LDS classes of mprg_kmeans_prepare (+ the global-memory form)
 
@@ -296,18 +297,25 @@ class ForestEngine(BatchEngine):
             hk = self._step("kloop_advance", k, n_hdr=HDR)
             if k > MAX_CLUSTERS or hk[83] == 0:
                 break
-            # the round's fits, already sorted into launch lists by the control step
-            for c, (entry, cls) in enumerate(KM_LISTS):
-                n_c = int(hk[86 + c])
-                if not n_c:
-                    continue
+            # the round's fits, already sorted into launch lists by the control step; the lists are independent launches of
+            # different kernels: side by side on side streams, so that one list's tail (its last, longest fits) overlaps the others
+            todo = [(c, int(hk[86 + c])) for c in range(len(KM_LISTS)) if hk[86 + c]]
+            n_side = len(todo) if (len(todo) > 1 and KM_SIDE_STREAMS and be.n_side_streams >= len(todo)) else 0
+            if n_side:
+                be.fork(n_side)
+            for q, (c, n_c) in enumerate(todo):
+                entry, cls = KM_LISTS[c]
                 lst = be.ptr(d_fl) + 4 * c * P
+                stream = be.side_ptr(q) if n_side else be.stream
+                outs = out_args[:-1] + (stream,)
                 if cls is None:
-                    be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, 0, 0, 0, 0, *out_args)
+                    be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, 0, 0, 0, 0, *outs, side=q if n_side else None)
                 else:
-                    be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, cls, N_INIT, *fit_args, *out_args)
+                    be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, cls, N_INIT, *fit_args, *outs, side=q if n_side else None)
                 km_events.append(self._last_event(entry))
                 self.counters["launches"] += 1
+            if n_side:
+                be.join(n_side)
             self._cluster_further(d_sub, d_ptab, P, k, dd, d_labels, d_assign, d_wc, n_wc, d_wr, n_wr, d_scratch, d_further, d_info, d_kinfo)
             cf_events.append(self._last_event("mprg_cluster_further"))
         # ---- S7: MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)

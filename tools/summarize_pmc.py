@@ -17,10 +17,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import KERNEL_OF, source_digest  # noqa: E402
 
 
+def kname(raw: str) -> str:
+    """'void k_x<36>(long const*, ...)' -> 'k_x' (template instantiations of one kernel are summed)."""
+    name = raw.split("(")[0].strip()
+    if name.startswith("void "):
+        name = name[5:]
+    return name.split("<")[0]
+
+
 def per_kernel(path):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].split("(")[0]
+        name = kname(r["Kernel_Name"])
         agg[name][0] += 1
         agg[name][1] += float(r["Counter_Value"])
     return agg
@@ -28,7 +36,16 @@ def per_kernel(path):
 
 def main():
     stats_csv, fetch_csv, write_csv, bench_json, out_json = sys.argv[1:6]
-    stats = {r["Name"].split("(")[0]: r for r in csv.DictReader(open(stats_csv))}
+    stats = {}
+    for r in csv.DictReader(open(stats_csv)):          # template instantiations of one kernel: calls and time added up
+        n_ = kname(r["Name"])
+        if n_ in stats:
+            a = stats[n_]
+            calls = int(a["Calls"]) + int(r["Calls"])
+            tot = float(a["TotalDurationNs"]) + float(r["TotalDurationNs"])
+            a.update(Calls=str(calls), TotalDurationNs=str(tot), AverageNs=str(tot / calls), Percentage=str(float(a["Percentage"]) + float(r["Percentage"])))
+        else:
+            stats[n_] = dict(r)
     fetch, write = per_kernel(fetch_csv), per_kernel(write_csv)
     bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
     alg = {}
@@ -63,7 +80,7 @@ def main():
     # per-kernel figures are ONE pass (the exclusive one): compare per pass.  The number of passes comes from the dominant
     # entry point, whose kernel is launched exactly once per call.
     top_names, top = groups[bench["roofline"]["entry_point"]]
-    passes = max(1, round(out[top_names[0]]["launches"] / max(top["launches"], 1)))
+    passes = max(1, round(sum(out[n_]["launches"] for n_ in top_names if n_ in out) / max(top["launches"], 1)))
     for ep, (names, k) in groups.items():
         hbm = sum(out.get(n, {}).get("hbm_bytes_per_launch", 0) * out.get(n, {}).get("launches", 0) for n in names) / passes
         hbm_raw = sum(out.get(n, {}).get("hbm_bytes_per_launch_raw", 0) * out.get(n, {}).get("launches", 0) for n in names) / passes
@@ -79,7 +96,7 @@ def main():
         entry[ep] = rec
     json.dump(dict(source_digest=source_digest(), fetch_correction="2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes)",
                    sources=dict(stats=stats_csv, fetch=fetch_csv, write=write_csv, bench=bench_json),
-                   bench_config=dict(batch=bench["config"]["batch_per_gpu"], workers=bench["config"]["host_worker_processes_per_gpu"],
+                   bench_config=dict(batch=bench["config"]["alignments_per_step"], workers=bench["config"]["host_worker_processes_per_gpu"],
                                      streams=bench["config"]["streams_per_worker"]),
                    kernels=out, entry_points=entry), open(out_json, "w"), indent=1)
     print(json.dumps(entry, indent=1))
