@@ -46,7 +46,9 @@ KM_LISTS = (("mprg_kmeans_fit_wave", 0), ("mprg_kmeans_fit_wave", 1), ("mprg_kme
             ("mprg_kmeans_fit", None), ("mprg_kmeans_fit_small", 0), ("mprg_kmeans_fit_small", 1))
 # which forms small fits take: bit 0 wave form (measured slower on MI355X: profiles/r03/kmeans_forms.md), bit 1 small workgroups
 KM_MODE = int(os.environ.get("MPRG_KM_MODE", "2"))
-XX
+# a round's launch lists side by side on side streams: measured flat on MI355X (352 vs 354 ms per forest of 30 000 alignments,
+# profiles/r03/kmeans_forms.md), off by default
+KM_SIDE_STREAMS = os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0"
 F_FIELDS = 96
 PREPARE_CLASSES = 4                      # LDS classes of mprg_kmeans_prepare (+ the global-memory form)
 
