@@ -25,7 +25,9 @@ def main(argv=None):
                               "Default: %(default)s")
         par.add_argument("-F", "--force", action="store_true", default=False, help="Force overwrite previous output")
         par.add_argument("-t", "--threads", action="store", type=int, default=1,
-                         help="Number of threads. 0 will use all available. Default: %(default)d")
+                         help="Number of threads (from_msa: host threads of the parser / encoders / writers on one GPU, host worker "
+                              "processes per GPU under torchrun; update: concurrent aligner calls). 0 will use all available. "
+                              "Default: %(default)d")
         par.add_argument("-v", "--verbose", action="count", default=0, help="Increase output verbosity")
         par.add_argument("--log", help="Path to write log to. Default is stderr")
     args = parser.parse_args(argv)
@@ -33,11 +35,14 @@ def main(argv=None):
         level = [logging.INFO, logging.DEBUG, logging.DEBUG][min(args.verbose, 2)]
         logging.basicConfig(level=level, **({"filename": args.log} if args.log else {"stream": sys.stderr}))
         if args.threads == 0:
-            # "all available": host worker processes per GPU stop paying at ~10 (16 are slower than 10 —
-            # the processes' queues are time-sliced on the one device), and the ranks of a node share its cores
+            # "all available": the CPUs this process may use, shared by the ranks of a node.  from_msa: host threads of the
+            # native batch stages (one GPU) or host worker processes per GPU (several ranks), where more than ~10 stop paying;
+            # update: threads that wait for aligner processes — no such cap
             local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
             from .utils.misc import effective_cpus
-            args.threads = max(1, min(MAX_WORKERS_PER_GPU, effective_cpus() // local_world))
+            args.threads = max(1, effective_cpus() // local_world)
+            if args.func is from_msa.run and local_world > 1:
+                args.threads = min(args.threads, MAX_WORKERS_PER_GPU)
         args.func(args)
     else:
         parser.print_help()

@@ -63,6 +63,21 @@ def apply_variants(builder, update_data_list) -> tuple:
     return sorted(leaves, key=lambda node: node.node_id), ok, failed
 
 
+class _LazyAligner:
+    """The aligner, constructed at its first call (NotAValidExecutableError only if an alignment is actually needed)."""
+
+    def __init__(self, factory):
+        self._factory, self._aligner = factory, None
+        import threading
+        self._lock = threading.Lock()
+
+    def get_updated_alignment(self, current_alignment, new_sequences):
+        with self._lock:
+            if self._aligner is None:
+                self._aligner = self._factory()
+        return self._aligner.get_updated_alignment(current_alignment=current_alignment, new_sequences=new_sequences)
+
+
 def run(cl_options, aligner=None):
     """aligner: an object with get_updated_alignment(current_alignment, new_sequences) (tests pass a ReplayAligner);
     default: --aligner-replay FILE if given, else MAFFT."""
@@ -72,9 +87,16 @@ def run(cl_options, aligner=None):
         raise RuntimeError("One or more output files already exists, aborting run...")
     output_dir = Path(options.output_prefix).parent
     output_dir.mkdir(parents=True, exist_ok=True)
+    msa_temp = None
     if aligner is None:
         replay = getattr(options, "aligner_replay", None)
-        aligner = ReplayAligner.from_file(replay) if replay else MAFFT(tmpdir=output_dir / "msa_temp")
+        if replay:
+            aligner = ReplayAligner.from_file(replay)
+        else:
+            # made when the first leaf asks for it: an update that touches no leaf needs no MAFFT (this package ships none),
+            # and its temp directory goes when the run ends (the reference: a temp root + remove_empty_folders)
+            msa_temp = output_dir / "msa_temp"
+            aligner = _LazyAligner(lambda: MAFFT(tmpdir=msa_temp))
     db = PrgBuilderZipDatabase(options.update_DS)
     try:
         logger.info("Reading update data structures...")
@@ -118,6 +140,9 @@ def run(cl_options, aligner=None):
         prg = builder.build_prg()
         out[locus] = locus_record(locus, prg, builder, options.output_type)
     write_final_files(out, options.output_type, options.output_prefix)
+    if msa_temp is not None and msa_temp.exists():
+        import shutil
+        shutil.rmtree(msa_temp, ignore_errors=True)
     logger.info(f"Number of variants successfully applied: {n_ok}")
     logger.warning(f"Number of variants that failed to be applied: {n_failed}")
     logger.info("All done!")
