@@ -41,7 +41,8 @@ enum { MPRG_IV_MATCH = 0, MPRG_IV_NONMATCH = 1 /* bit 0 of a triple's type word 
 enum { MPRG_ST_PARTITION_ERROR = 1, MPRG_ST_ALL_N_SLICE = 2,
        MPRG_ST_BAD_LAUNCH = 4 /* a view of fused_list does not satisfy the fused launch shape: a host error, not a property of the data */ };
 /* per-fit status bits written by the KMeans kernels */
-enum { MPRG_KM_RELOCATED = 1 /* an empty cluster was relocated (info) */, MPRG_KM_UNSUPPORTED = 2 /* error */ };
+enum { MPRG_KM_RELOCATED = 1 /* an empty cluster was relocated (info) */,
+       MPRG_KM_UNSUPPORTED = 2 /* error: the relocation's selection ran out of frames (more than 5^10 samples) */ };
 
 const char *mprg_version(void);
 const char *mprg_last_error(void);
@@ -190,6 +191,11 @@ int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, const int32_t *fi
  * (km_info, km_status) stay indexed by the kinfo row.  lds_class: mprg_kmeans_wave_class(D, V, k) of every fit of the launch
  * (0..3: 7.4 / 13.6 / 23.8 / 38.1 KB regions; -1: the fit needs the workgroup form).  The final centres of the best restart
  * pass through restart slot 0 of the problem's workspace. */
+/* np.argpartition(values, kth) as scikit-learn's empty-cluster relocation calls it (_k_means_common.pyx:167-211, float64, no
+ * NaN): the generic arg-introselect of the reference's locked NumPy 1.24 including its median-of-medians fallback.  perm
+ * (int32 [n]) receives the permutation, ok[0] = 1 (0: more than 5^10 elements).  Exposed for its own parity test; the KMeans
+ * kernels run the same code inside a fit. */
+int mprg_argpartition(const double *values, int32_t *perm, int n, int kth, int32_t *ok, void *stream);
 int mprg_kmeans_wave_class(int64_t D, int64_t V, int k);
 /* A11, the workgroup form for SMALL fits: 128-thread workgroups with a trimmed static LDS (8 KB pool; small_class 0 also a
  * 6 x 6 centre-centre table, i.e. k <= 6), so that 6-8 fits are resident per CU instead of 4.  mprg_kmeans_small_class(D, V, k,

@@ -216,6 +216,12 @@ int mprg_kmeans_fit_wave(const int64_t *prob, const int32_t *kinfo, const int32_
   return check_launch("k_kmeans_fit_wave");
 }
 
+int mprg_argpartition(const double *values, int32_t *perm, int n, int kth, int32_t *ok, void *stream) {
+  if (n <= 0 || kth < 0 || kth >= n) return fail("mprg_argpartition: kth out of range");
+  LAUNCH(k_argpartition, 1, 64, stream, values, perm, n, kth, ok);
+  return check_launch("k_argpartition");
+}
+
 int mprg_kmeans_small_class(int64_t D, int64_t V, int k, int n_init) {
   if (k < 2 || k > KM_KMAX || n_init > KMS_RMAX || n_init * D > KMS_LAB8) return -1;
   long long vp = (V + 3) & ~3LL; if (((vp >> 2) & 1) == 0) vp += 4;

@@ -614,8 +614,7 @@ class BatchEngine:
             info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
             labels_all = be.download(d_labels, np.int32, lo)
             if (st & 2).any():
-                raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
-                                "is not restated on the device; refusing to continue with a possibly different result")
+                raise MprgError("KMeans empty-cluster relocation: the selection ran out of frames (more than 5^10 samples in a fit)")
             nxt = []
             for a, i in enumerate(active):
                 p = probs[i]

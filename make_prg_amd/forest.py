@@ -329,8 +329,7 @@ class ForestEngine(BatchEngine):
               "mprg_kmeans_fit_small": float(h[93:94].view(np.float64)[0])}
         km_bytes = sum(kb.values())
         if h[82]:
-            raise MprgError("KMeans empty-cluster relocation needed NumPy's median-of-medians selection fallback, which "
-                            "is not restated on the device; refusing to continue with a possibly different result")
+            raise MprgError("KMeans empty-cluster relocation: the selection ran out of frames (more than 5^10 samples in a fit)")
         self.counters["fits"] += fits
         self.counters["kmeans_bytes"] += km_bytes
         # algorithmic bytes are known only after the fits: 8 D V (iterations + n_init)

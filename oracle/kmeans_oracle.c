@@ -534,6 +534,9 @@ static double single_elkan(const km_t *p, double *centers /* in: init, out: fina
 }
 
 /* _k_means_common.pyx:314-328 */
+/* exported for the pinning test of the selection alone (tests/test_argpartition.py): perm[0..num) = 0..num-1 on entry */
+void mprg_oracle_argpartition(const double *v, long *perm, long num, long kth) { np_argpartition(v, perm, num, kth); }
+
 static int same_clustering(const int *l1, const int *l2, int n, int k) {
   int map[16];
   for (int j = 0; j < k; j++) map[j] = -1;

@@ -55,6 +55,12 @@ def test_kmeans_known_answers_persistent_workgroups(hip, golden_kmeans):
             assert g["n_iter"] == f["n_iter"]
 
 
+def test_argpartition_with_median_of_medians_fallback(hip):
+    """np.argpartition of the relocation on adversarial inputs (answers of the real NumPy, generic introselect)."""
+    from tests.test_argpartition import check_device
+    assert check_device(hip) == 9
+
+
 def test_kmer_sizes_above_16(hip):
     """-L 17 / 20 / 24 / 33: the real reference's answers (verified hash keys in the k-mer dictionary)."""
     from tests.long_kmer_common import check_long_kmers
