@@ -408,6 +408,20 @@ int mprg_write_pieces_host(int fd, const long long *addr, const long long *len, 
 void mprg_crc32_members_host(const long long *addr, const long long *len, const long long *first, long long n_members, int n_threads,
                              uint32_t *crc);
 
+/* one-pass form of mprg_encode_sizes/fill_host: every locus encoded once into memory of an encode POOL (blocks owned by the
+ * pool, reused after _reset); per locus the ADDRESS and size of its binary PRG / GFA text (-1 sizes: not covered by the one-pass
+ * encoders) and the three CRCs.  The containers are written from address tables (mprg_write_pieces_host).  0, or -1: out of memory.
+ * _info: {bytes mapped, bytes handed out since the last reset}. */
+void *mprg_encode_pool_new_host(void);
+void mprg_encode_pool_reset_host(void *pool);
+void mprg_encode_pool_free_host(void *pool);
+void mprg_encode_pool_info_host(void *pool, long long *info);
+int mprg_encode_batch_host(void *pool, const char *prg, const long long *base, const long long *len, long long n, int n_threads,
+                           int want_bin, int want_gfa, long long *bin_addr, long long *bin_words, long long *gfa_addr,
+                           long long *gfa_bytes, uint32_t *crc);
+/* running CRC-32 of one buffer, zlib.crc32(data, crc) (carry-less-multiplication folding where the host has PCLMULQDQ) */
+uint32_t mprg_crc32_host(uint32_t crc, const void *data, long long len);
+
 #ifdef __cplusplus
 }
 #endif

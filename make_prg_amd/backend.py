@@ -76,6 +76,12 @@ SIGNATURES = {
     "mprg_encode_fill_host": (None, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int] + [c_void_p] * 7),
     "mprg_crc32_members_host": (None, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p]),
     "mprg_write_pieces_host": (c_int, [c_int, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int]),
+    "mprg_encode_pool_new_host": (c_void_p, []),
+    "mprg_encode_pool_reset_host": (None, [c_void_p]),
+    "mprg_encode_pool_free_host": (None, [c_void_p]),
+    "mprg_encode_pool_info_host": (None, [c_void_p, c_void_p]),
+    "mprg_encode_batch_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_int] + [c_void_p] * 5),
+    "mprg_crc32_host": (c_uint32, [c_uint32, c_void_p, ctypes.c_longlong]),
 }
 
 

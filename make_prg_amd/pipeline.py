@@ -34,12 +34,24 @@ logger = logging.getLogger("make_prg_amd")
 CHUNK = int(os.environ.get("MPRG_CHUNK", "4096"))          # alignment files per resident batch
 DEPTH = 3                                                  # chunks in flight: build | encode | write
 TRACE = os.environ.get("MPRG_PIPELINE_TRACE", "") not in ("", "0")
+# threads that write one container side by side: buffered writes to ONE file take the inode's lock in turn (tools/write_probe.py:
+# 1 / 4 / 16 threads on a file all reach ~10 GB/s), so more than two only spin on that lock
+WRITE_THREADS = int(os.environ.get("MPRG_WRITE_THREADS", "2"))
 
 
 def _trace(msg):
     if TRACE:
         import sys
         sys.stderr.write("[pipeline] " + msg + "\n")
+
+
+def since_process_start() -> float:
+    """Seconds since this process was created (/proc: start time in clock ticks since boot against the uptime)."""
+    with open("/proc/self/stat") as fh:
+        ticks = int(fh.read().rsplit(")", 1)[1].split()[19])
+    with open("/proc/uptime") as fh:
+        up = float(fh.read().split()[0])
+    return up - ticks / os.sysconf("SC_CLK_TCK")
 
 
 def sort_key(path: Path) -> str:
@@ -56,11 +68,22 @@ class _Outputs:
         self.threads = threads
         self.n = 0
         self.last = None
+        self.pools = {}
+        self.lib = None
+
+    def pool(self, lib, slot):
+        """The encode pool of a chunk slot (chunks DEPTH apart share one: the earlier one's members are on disk by then)."""
+        self.lib = lib
+        if slot not in self.pools:
+            self.pools[slot] = lib.mprg_encode_pool_new_host()
+        else:
+            lib.mprg_encode_pool_reset_host(self.pools[slot])
+        return self.pools[slot]
 
     def zip(self, kind):
         if kind not in self.zips:
             name = f"{self.prefix}.update_DS.zip" if kind == "pickle" else f"{self.prefix}.prg.{kind}.zip"
-            self.zips[kind] = StoredZipWriter(name, threads=max(2, min(8, self.threads)))
+            self.zips[kind] = StoredZipWriter(name, threads=WRITE_THREADS)
         return self.zips[kind]
 
     def plan_fa(self, addr, ln, lib, threads: int):
@@ -80,6 +103,9 @@ class _Outputs:
         return run
 
     def close(self):
+        for pool in self.pools.values():
+            self.lib.mprg_encode_pool_free_host(pool)
+        self.pools = {}
         if self.fa_fd is not None:
             os.close(self.fa_fd)
         for z in self.zips.values():
@@ -109,6 +135,10 @@ def run_pipeline(files: List[Path], options, backend) -> int:
     backend: a backend object, or a function that makes one — it is called AFTER the ingest thread has started, so that reading
     and parsing the first chunks overlaps importing torch and bringing up the device (~2 s of a command-line run)."""
     from .subcommands import from_msa as drv
+    if TRACE:
+        import atexit
+        _trace(f"pipeline starts {since_process_start():.2f} s after the process ({len(files)} files)")
+        atexit.register(lambda: _trace(f"interpreter exits {since_process_start():.2f} s after the process started"))
     lib = native.library()
     if lib is None:
         raise RuntimeError("libmprg_host.so is missing: build it with `python __graft_entry__.py`")
@@ -121,9 +151,9 @@ def run_pipeline(files: List[Path], options, backend) -> int:
     q_in: "queue.Queue" = queue.Queue(maxsize=2)
     q_out: "queue.Queue" = queue.Queue()
     errors: List[BaseException] = []
-    # a chunk's pinned buffers (arena, PRG text, tree export: DEPTH of each, used in turn) are read by the output stages until
-    # its members are written: the build of chunk i + DEPTH starts only when the writes of chunk i are done
-    in_flight = threading.Semaphore(DEPTH)
+    # a chunk's buffers (pinned arena, PRG text, tree export, encode pool: DEPTH of each, chunk i uses slot i % DEPTH) are read by
+    # the output stages until its members are written: the build of chunk i + DEPTH starts only when the writes of chunk i are done
+    slot_free = [threading.Semaphore(1) for _ in range(DEPTH)]
     writers = ThreadPoolExecutor(int(os.environ.get("MPRG_WRITERS", "4")))
 
     def stage_ingest():
@@ -149,6 +179,7 @@ def run_pipeline(files: List[Path], options, backend) -> int:
                 item = q_out.get()
                 if item is None:
                     break
+                slot = slot_free[item[0]["ci"] % DEPTH]
                 jobs = _write_chunk(lib, out, options, threads, *item)
                 # the containers are written side by side while the next chunk is encoded; the chunk's buffers are free again
                 # once all of them are done
@@ -156,29 +187,32 @@ def run_pipeline(files: List[Path], options, backend) -> int:
                 pending = [len(futs)]
                 lock = threading.Lock()
 
-                def done(f, pending=pending, lock=lock):
+                def done(f, pending=pending, lock=lock, slot=slot):
                     if f.exception() is not None:
                         errors.append(f.exception())
                     with lock:
                         pending[0] -= 1
                         last = pending[0] == 0
                     if last:
-                        in_flight.release()
+                        slot.release()
 
                 if not futs:
-                    in_flight.release()
+                    slot.release()
                 for f in futs:
                     f.add_done_callback(done)
         except BaseException as err:
             errors.append(err)
-            in_flight.release()
+            for sl in slot_free:          # nothing more is written: let the build loop run out
+                sl.release()
             while q_out.get() is not None:
-                in_flight.release()
+                for sl in slot_free:
+                    sl.release()
 
     t_in, t_out = threading.Thread(target=stage_ingest, daemon=True), threading.Thread(target=stage_output, daemon=True)
     t_in.start()
     t_out.start()
     be = backend() if callable(backend) else backend
+    _trace(f"device ready {since_process_start():.2f} s after the process started") if TRACE else None
     be.async_depth = DEPTH
     try:
         while True:
@@ -186,7 +220,7 @@ def run_pipeline(files: List[Path], options, backend) -> int:
             if item is None or errors:
                 break
             ci, chunk, h, info = item
-            in_flight.acquire()
+            slot_free[ci % DEPTH].acquire()
             if errors:
                 break
             q_out.put(_build_chunk(lib, be, options, threads, ci, chunk, h, info))
@@ -197,6 +231,7 @@ def run_pipeline(files: List[Path], options, backend) -> int:
     if errors:
         raise errors[0]
     out.close()
+    _trace(f"outputs closed {since_process_start():.2f} s after the process started") if TRACE else None
     return out.n
 
 
@@ -292,18 +327,15 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
             logger.warning(f"Skipping building PRG for {names[int(fi[j])]}. Error: {err}")
         whole = np.frombuffer(fin.buffer, np.uint8) if len(fin.buffer) else np.zeros(1, np.uint8)
         keep.append(whole)
+        # every locus encoded once, into the chunk's encode pool; members are written from the addresses
         bin_words, gfa_bytes = np.zeros(n_fast, np.int64), np.zeros(n_fast, np.int64)
-        lib.mprg_encode_sizes_host(whole.ctypes.data, base.ctypes.data, length.ctypes.data, n_fast, threads, int(ot.binary),
-                                   int(ot.gfa), bin_words.ctypes.data, gfa_bytes.ctypes.data)
-        bw, gb = np.maximum(bin_words, 0), np.maximum(gfa_bytes, 0)
-        bin_off, gfa_off = np.cumsum(bw) - bw, np.cumsum(gb) - gb
-        bin_buf = np.empty(max(int(bw.sum()), 1), np.uint32) if ot.binary else None
-        gfa_buf = np.empty(max(int(gb.sum()), 1), np.uint8) if ot.gfa else None
-        keep += [bin_buf, gfa_buf]
+        bin_addr, gfa_addr = np.zeros(n_fast, np.int64), np.zeros(n_fast, np.int64)
         crc = np.zeros((n_fast, 3), np.uint32)
-        lib.mprg_encode_fill_host(whole.ctypes.data, base.ctypes.data, length.ctypes.data, n_fast, threads,
-                                  bin_buf.ctypes.data if ot.binary else None, bin_off.ctypes.data, bin_words.ctypes.data,
-                                  gfa_buf.ctypes.data if ot.gfa else None, gfa_off.ctypes.data, gfa_bytes.ctypes.data, crc.ctypes.data)
+        pool = out.pool(lib, res["ci"] % DEPTH)
+        if lib.mprg_encode_batch_host(pool, whole.ctypes.data, base.ctypes.data, length.ctypes.data, n_fast, threads, int(ot.binary),
+                                      int(ot.gfa), bin_addr.ctypes.data, bin_words.ctypes.data, gfa_addr.ctypes.data,
+                                      gfa_bytes.ctypes.data, crc.ctypes.data) != 0:
+            raise MemoryError("the encoders' pool could not grow")
         t_addr[fi], t_len[fi] = whole.ctypes.data + base, length
     tw2 = time.perf_counter()
     # ---- the loci of the object path and the PRGs the one-pass encoders do not cover: bytes, one by one (rare)
@@ -348,7 +380,7 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
             member_names = member_names + [nm]
             crcs = np.concatenate([crcs, [zlib.crc32(data)]])
         if len(member_names):
-            jobs.append(timed(kind, out.zip(kind).plan_table(member_names, addr, ln, crcs, lib, max(2, min(8, threads)), keep)))
+            jobs.append(timed(kind, out.zip(kind).plan_table(member_names, addr, ln, crcs, lib, WRITE_THREADS, keep)))
 
     # ---- <prefix>.prg.fa: ">locus\n" PRG "\n" per built locus, in order
     if ot.prg and len(built):
@@ -361,19 +393,19 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
         addr[:, 1], ln[:, 1] = t_addr[built], t_len[built]
         addr[:, 2], ln[:, 2] = blob.ctypes.data + blob.size - 1, 1
         keep.append(blob)
-        jobs.append(timed("prg.fa", out.plan_fa(addr.reshape(-1), ln.reshape(-1), lib, max(2, min(8, threads)))))
+        jobs.append(timed("prg.fa", out.plan_fa(addr.reshape(-1), ln.reshape(-1), lib, WRITE_THREADS)))
     # ---- zip members of the arena path's loci
     okj = np.nonzero(ok)[0]
     ok_names = [names[i] for i in fi[okj].tolist()] if n_fast else []
     if ot.binary:
         sel = okj[bin_words[okj] >= 0] if n_fast else okj
         zip_job("bin", [names[i] + ".bin" for i in fi[sel].tolist()] if n_fast else [],
-                (bin_buf.ctypes.data + 4 * bin_off[sel]).reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64),
+                bin_addr[sel].reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64),
                 (4 * bin_words[sel]).reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64), crc[sel, 1] if n_fast else np.zeros(0, np.uint32))
     if ot.gfa:
         sel = okj[gfa_bytes[okj] >= 0] if n_fast else okj
         zip_job("gfa", [names[i] + ".gfa" for i in fi[sel].tolist()] if n_fast else [],
-                (gfa_buf.ctypes.data + gfa_off[sel]).reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64),
+                gfa_addr[sel].reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64),
                 gfa_bytes[sel].reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64), crc[sel, 2] if n_fast else np.zeros(0, np.uint32))
     if ot.prg:          # update_DS members: header + slices of the arena, the titles and the device's tree export
         K = 7

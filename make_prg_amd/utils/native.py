@@ -26,6 +26,12 @@ HOST_SIGNATURES = {
     "mprg_encode_fill_host": (None, [_P, _P, _P, _LL, ctypes.c_int] + [_P] * 7),
     "mprg_crc32_members_host": (None, [_P, _P, _P, _LL, ctypes.c_int, _P]),
     "mprg_write_pieces_host": (ctypes.c_int, [ctypes.c_int, _P, _P, _P, _LL, ctypes.c_int]),
+    "mprg_encode_pool_new_host": (_P, []),
+    "mprg_encode_pool_reset_host": (None, [_P]),
+    "mprg_encode_pool_free_host": (None, [_P]),
+    "mprg_encode_pool_info_host": (None, [_P, _P]),
+    "mprg_encode_batch_host": (ctypes.c_int, [_P, _P, _P, _P, _LL, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [_P] * 5),
+    "mprg_crc32_host": (ctypes.c_uint32, [ctypes.c_uint32, _P, _LL]),
 }
 _lib = None
 _tried = False

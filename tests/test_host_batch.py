@@ -1,0 +1,98 @@
+"""libmprg_host.so's batch stages on their own (no GPU): the folding CRC-32 against zlib, the pooled one-pass encoders against
+the per-locus encoders, pool reuse."""
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+from make_prg_amd.utils import native
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = native.library()
+    if lib is None:
+        pytest.skip("libmprg_host.so not built")
+    return lib
+
+
+def test_crc32_equals_zlib(lib):
+    rng = np.random.default_rng(7)
+    for n in list(range(0, 300)) + [1023, 4096, 65543, (1 << 20) + 5]:
+        data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        for start in (0, 0x12345678):
+            assert lib.mprg_crc32_host(start, data, n) == zlib.crc32(data, start), (n, start)
+    # a running CRC over pieces of awkward sizes
+    data = rng.integers(0, 256, 100000, dtype=np.uint8).tobytes()
+    c, at = 0, 0
+    for piece in (1, 63, 64, 65, 15, 16, 17, 1000, 33333):
+        c = lib.mprg_crc32_host(c, data[at:at + piece], piece)
+        at += piece
+    assert c == zlib.crc32(data[:at])
+
+
+def _random_prg(rnd, depth=0, site=[5]):
+    def dna(lo, hi):
+        return "".join(rnd.choice("ACGT") for _ in range(rnd.randint(lo, hi)))
+    out = [dna(1, 40)]
+    for _ in range(rnd.randint(1, 4)):
+        s = site[0]
+        site[0] += 2
+        alleles = []
+        for _ in range(rnd.randint(2, 4)):
+            alleles.append(_random_prg(rnd, depth + 1, site) if depth < 2 and rnd.random() < 0.3 else dna(0 if depth else 1, 30))
+        out.append(f" {s} " + f" {s + 1} ".join(alleles) + f" {s} " + dna(1, 40))
+    return "".join(out)
+
+
+def test_encode_batch_equals_per_locus(lib):
+    rnd = random.Random(3)
+    prgs = []
+    for i in range(300):
+        prgs.append(_random_prg(rnd, 0, [5]).encode())
+    prgs[17] = b"ACGT 5 A 6 C 5 N"                 # not plain for the binary encoder (N), GFA takes it
+    prgs[40] = b"AC 7 A 8 C 7 G"                   # sites must start at 5: not plain for the GFA form
+    prgs[99] = ("A" * (40 << 20)).encode()         # one locus bigger than a pool block
+    text = np.frombuffer(b"".join(prgs), np.uint8)
+    length = np.array([len(p) for p in prgs], np.int64)
+    base = np.cumsum(length) - length
+    length[5] = -1                                  # no PRG for this locus
+    n = len(prgs)
+    pool = lib.mprg_encode_pool_new_host()
+    try:
+        for round_ in range(2):                     # the second round reuses the blocks
+            if round_:
+                lib.mprg_encode_pool_reset_host(pool)
+            ba, bw, ga, gb = (np.zeros(n, np.int64) for _ in range(4))
+            crc = np.zeros((n, 3), np.uint32)
+            assert lib.mprg_encode_batch_host(pool, text.ctypes.data, base.ctypes.data, length.ctypes.data, n, 5, 1, 1, ba.ctypes.data,
+                                              bw.ctypes.data, ga.ctypes.data, gb.ctypes.data, crc.ctypes.data) == 0
+            import ctypes
+            for i, p in enumerate(prgs):
+                if length[i] < 0:
+                    assert bw[i] == -1 and gb[i] == -1
+                    continue
+                want_bin = native.prg_encode(p)
+                want_gfa = native.gfa_text(p)
+                assert crc[i, 0] == zlib.crc32(p)
+                if want_bin is None:
+                    assert bw[i] == -1
+                else:
+                    got = ctypes.string_at(int(ba[i]), int(4 * bw[i]))
+                    assert got == np.asarray(want_bin, "<u4").tobytes()
+                    assert crc[i, 1] == zlib.crc32(got)
+                if want_gfa is None:
+                    assert gb[i] == -1
+                else:
+                    got = ctypes.string_at(int(ga[i]), int(gb[i]))
+                    assert got == (want_gfa if isinstance(want_gfa, bytes) else want_gfa.encode())
+                    assert crc[i, 2] == zlib.crc32(got)
+            info = np.zeros(2, np.int64)
+            lib.mprg_encode_pool_info_host(pool, info.ctypes.data)
+            if round_ == 0:
+                mapped = int(info[0])
+            else:
+                assert int(info[0]) == mapped       # nothing new was mapped for the same work
+    finally:
+        lib.mprg_encode_pool_free_host(pool)

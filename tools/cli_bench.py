@@ -1,5 +1,6 @@
 """GPU-box helper: end-to-end wall time of the command line (files on disk -> .prg.fa / .bin.zip / .gfa.zip / update_DS.zip)
-for N synthetic config-C alignments.  usage: cli_bench.py [N] [threads] [output types ...]"""
+for N synthetic config-C alignments.  usage: cli_bench.py [N] [threads] [output types ...]; an output type may carry environment
+settings for its run: a:MPRG_WRITE_THREADS=1,MPRG_CHUNK=2048"""
 import os
 import subprocess
 import sys
@@ -26,11 +27,15 @@ if __name__ == "__main__":
         os.mkdir(d)
         with Pool(32) as pool:
             pool.map(_write, [(d, s) for s in range(n)], chunksize=16)
-        for ot in types:
+        for run, spec in enumerate(types):
+            ot, _, envs = spec.partition(":")
+            env = dict(os.environ, **dict(kv.split("=", 1) for kv in envs.split(",") if kv))
             t0 = time.time()
-            res = subprocess.run([sys.executable, "-m", "make_prg_amd", "from_msa", "-i", d, "-o", os.path.join(tmp, f"out_{ot}", "pan"),
-                                  "-t", t, "-O", ot, "--log", os.path.join(tmp, "log.txt")], cwd=root, capture_output=True, text=True)
+            res = subprocess.run([sys.executable, "-m", "make_prg_amd", "from_msa", "-i", d, "-o", os.path.join(tmp, f"out_{run}", "pan"),
+                                  "-t", t, "-O", ot, "--log", os.path.join(tmp, "log.txt")], cwd=root, capture_output=True, text=True, env=env)
             dt = time.time() - t0
-            print(f"-O {ot} -t {t}: {n} files in {dt:.1f}s = {n / dt:.0f} loci/s (rc {res.returncode}) {res.stderr[-300:] if res.returncode else ''}", flush=True)
+            import shutil
+            shutil.rmtree(os.path.join(tmp, f"out_{run}"), ignore_errors=True)
+            print(f"-O {ot} {envs} -t {t}: {n} files in {dt:.1f}s = {n / dt:.0f} loci/s (rc {res.returncode}) {res.stderr[-300:] if res.returncode else ''}", flush=True)
             print("".join(l for l in res.stderr.splitlines(True) if l.startswith("[pipeline]")), end="")
             print("   " + " | ".join(l.split(":", 2)[-1].strip() for l in open(os.path.join(tmp, "log.txt")) if "built in" in l or "written in" in l)[-300:])
