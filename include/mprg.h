@@ -422,6 +422,32 @@ int mprg_encode_batch_host(void *pool, const char *prg, const long long *base, c
 /* running CRC-32 of one buffer, zlib.crc32(data, crc) (carry-less-multiplication folding where the host has PCLMULQDQ) */
 uint32_t mprg_crc32_host(uint32_t crc, const void *data, long long len);
 
+/* Device-memory, stream and event plumbing for hosts that bring no GPU framework of their own (a Go / C / Java host binding
+ * this header; this repository's command line, which starts ~1 s earlier without importing torch).  Thin calls into the HIP
+ * runtime the library is linked against.  Pointers: NULL on failure; ints: 0 or a negative code; mprg_last_error() says what.
+ * mprg_rt_host_malloc: page-locked host memory that kernels may also write (result headers).  mprg_rt_memcpy_async kinds below;
+ * pageable host memory makes a copy synchronous.  mprg_rt_event_query: 0 done, 1 not yet.  Streams are non-blocking streams;
+ * every kernel entry point above takes one as its `stream` argument. */
+enum { MPRG_RT_H2D = 1, MPRG_RT_D2H = 2, MPRG_RT_D2D = 3 };
+int mprg_rt_device_count(void);
+int mprg_rt_init(int device);
+void *mprg_rt_malloc(long long nbytes);
+int mprg_rt_free(void *p);
+void *mprg_rt_host_malloc(long long nbytes);
+int mprg_rt_host_free(void *p);
+void *mprg_rt_stream_create(void);
+int mprg_rt_stream_destroy(void *stream);
+int mprg_rt_stream_sync(void *stream);
+int mprg_rt_memcpy_async(void *dst, const void *src, long long nbytes, int kind, void *stream);
+int mprg_rt_memset_async(void *dst, int value, long long nbytes, void *stream);
+void *mprg_rt_event_create(int timing);
+int mprg_rt_event_destroy(void *event);
+int mprg_rt_event_record(void *event, void *stream);
+int mprg_rt_event_sync(void *event);
+int mprg_rt_event_query(void *event);
+int mprg_rt_stream_wait_event(void *stream, void *event);
+double mprg_rt_event_elapsed_ms(void *start, void *stop);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,3 +50,9 @@ def main(argv=None):
 
 if __name__ == "__main__":
     main()
+    if os.environ.get("MPRG_FAST_EXIT", "1") != "0":
+        # every output file is closed by now: skip the interpreter's and the runtimes' tear-down (un-pinning GBs of buffers)
+        logging.shutdown()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)

@@ -82,6 +82,24 @@ SIGNATURES = {
     "mprg_encode_pool_info_host": (None, [c_void_p, c_void_p]),
     "mprg_encode_batch_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_int] + [c_void_p] * 5),
     "mprg_crc32_host": (c_uint32, [c_uint32, c_void_p, ctypes.c_longlong]),
+    "mprg_rt_device_count": (c_int, []),
+    "mprg_rt_init": (c_int, [c_int]),
+    "mprg_rt_malloc": (c_void_p, [ctypes.c_longlong]),
+    "mprg_rt_free": (c_int, [c_void_p]),
+    "mprg_rt_host_malloc": (c_void_p, [ctypes.c_longlong]),
+    "mprg_rt_host_free": (c_int, [c_void_p]),
+    "mprg_rt_stream_create": (c_void_p, []),
+    "mprg_rt_stream_destroy": (c_int, [c_void_p]),
+    "mprg_rt_stream_sync": (c_int, [c_void_p]),
+    "mprg_rt_memcpy_async": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p]),
+    "mprg_rt_memset_async": (c_int, [c_void_p, c_int, ctypes.c_longlong, c_void_p]),
+    "mprg_rt_event_create": (c_void_p, [c_int]),
+    "mprg_rt_event_destroy": (c_int, [c_void_p]),
+    "mprg_rt_event_record": (c_int, [c_void_p, c_void_p]),
+    "mprg_rt_event_sync": (c_int, [c_void_p]),
+    "mprg_rt_event_query": (c_int, [c_void_p]),
+    "mprg_rt_stream_wait_event": (c_int, [c_void_p, c_void_p]),
+    "mprg_rt_event_elapsed_ms": (ctypes.c_double, [c_void_p, c_void_p]),
 }
 
 
@@ -289,3 +307,240 @@ class HipBackend(_Base):
             ev = self.torch.cuda.Event()
             ev.record(s_)
             self.stream_obj.wait_event(ev)
+
+
+class _RtBuffer:
+    """Device memory of HipRuntimeBackend: an address and a size.  Dropping the last reference hands the block back to the
+    backend's free lists (work enqueued earlier on the backend's stream runs before anything a later owner enqueues there)."""
+    __slots__ = ("mprg_addr", "nbytes", "_cap", "_owner", "__weakref__")
+
+    def __init__(self, owner, addr: int, cap: int, nbytes: int):
+        self._owner, self.mprg_addr, self._cap, self.nbytes = owner, addr, cap, nbytes
+
+    def __len__(self):
+        return self.nbytes
+
+    def __del__(self):
+        owner = self._owner
+        if owner is not None and owner._free is not None:
+            owner._free.setdefault(self._cap, []).append(self.mprg_addr)
+
+
+class _RtHostBuffer:
+    """Page-locked host memory of HipRuntimeBackend (freed with the backend: un-pinning is slow, these are few and reused)."""
+    __slots__ = ("mprg_addr", "nbytes", "array")
+
+    def __init__(self, addr: int, nbytes: int):
+        self.mprg_addr, self.nbytes = addr, nbytes
+        self.array = np.frombuffer((ctypes.c_ubyte * nbytes).from_address(addr), np.uint8)
+
+    def numel(self):
+        return self.nbytes
+
+
+class _RtEvent:
+    def __init__(self, lib, timing: bool):
+        self.lib = lib
+        self.h = lib.mprg_rt_event_create(int(timing))
+        if not self.h:
+            raise MprgError(f"event: {lib.mprg_last_error().decode()}")
+
+    def record(self, stream):
+        self.lib.mprg_rt_event_record(self.h, stream)
+
+    def synchronize(self):
+        self.lib.mprg_rt_event_sync(self.h)
+
+    def elapsed_time(self, other) -> float:
+        other.synchronize()
+        return self.lib.mprg_rt_event_elapsed_ms(self.h, other.h)
+
+    def __del__(self):
+        try:
+            self.lib.mprg_rt_event_destroy(self.h)
+        except Exception:
+            pass
+
+
+class HipRuntimeBackend(_Base):
+    """The same product backend without torch: device memory, page-locked host memory, streams and events through the library's
+    own mprg_rt_* calls (include/mprg.h), a size-class free list instead of torch's caching allocator.  The command line uses it
+    (a run starts ~1 s earlier: tools/startup_probe.py); anything that also needs torch.distributed keeps HipBackend."""
+    name = "hip (no torch)"
+
+    def __init__(self, device: Optional[int] = None, lib_path: str = HIP_LIB_PATH, own_stream: bool = True):
+        if not os.path.exists(lib_path):
+            raise MprgError(f"{lib_path} not found: build it with `python __graft_entry__.py build` (hipcc, gfx950)")
+        self._free = None
+        self.lib = bind(ctypes.CDLL(lib_path))
+        n = self.lib.mprg_rt_device_count()
+        if n <= 0:
+            raise MprgError("no ROCm device visible: make_prg_amd has no CPU fallback")
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % n
+        self._check(self.lib.mprg_rt_init(device), "device")
+        self.device = device
+        self.stream = self._ptr(self.lib.mprg_rt_stream_create(), "stream")
+        self._free = {}                       # capacity -> addresses ready for reuse
+        self._host = []                       # page-locked blocks, freed at close()
+        self._pending = []                    # (event, buffer): buffers the copy stream still reads
+        self.n_cus = self.lib.mprg_device_cus()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise MprgError(f"{what} failed ({rc}): {self.lib.mprg_last_error().decode()}")
+
+    def _ptr(self, p, what):
+        if not p:
+            raise MprgError(f"{what} failed: {self.lib.mprg_last_error().decode()}")
+        return p
+
+    def on_stream(self):
+        import contextlib
+        return contextlib.nullcontext()       # every entry point takes the stream explicitly
+
+    @staticmethod
+    def _capacity(nbytes: int) -> int:
+        """Size classes 1/8 of a power of two apart (at most 12.5 % unused), 512-byte floor."""
+        n = max(int(nbytes), 512)
+        step = 1 << max(n.bit_length() - 4, 9)
+        return (n + step - 1) // step * step
+
+    def empty(self, nbytes: int):
+        nbytes = max(int(nbytes), 16)
+        cap = self._capacity(nbytes)
+        free = self._free.get(cap)
+        if free:
+            return _RtBuffer(self, free.pop(), cap, nbytes)
+        addr = self.lib.mprg_rt_malloc(cap)
+        if not addr:          # give what the free lists hold back to the runtime and try once more
+            self.trim()
+            addr = self._ptr(self.lib.mprg_rt_malloc(cap), f"device allocation of {cap} bytes")
+        return _RtBuffer(self, addr, cap, nbytes)
+
+    def trim(self):
+        """hipFree of every block in the free lists (after waiting for the stream)."""
+        self.synchronize()
+        for cap, addrs in self._free.items():
+            for a in addrs:
+                self.lib.mprg_rt_free(a)
+        self._free = {}
+
+    def zeros(self, nbytes: int):
+        buf = self.empty(nbytes)
+        self._check(self.lib.mprg_rt_memset_async(buf.mprg_addr, 0, buf.nbytes, self.stream), "memset")
+        return buf
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes == 0:
+            return self.empty(16)
+        buf = self.empty(arr.nbytes)
+        self._check(self.lib.mprg_rt_memcpy_async(buf.mprg_addr, arr.ctypes.data, arr.nbytes, 1, self.stream), "upload")
+        self._check(self.lib.mprg_rt_stream_sync(self.stream), "upload")          # pageable source: it may go away after this call
+        return buf
+
+    def download(self, buf, dtype, count: int) -> np.ndarray:
+        out = np.empty(int(count), dtype)
+        if out.nbytes:
+            self._check(self.lib.mprg_rt_memcpy_async(out.ctypes.data, self.ptr(buf), out.nbytes, 2, self.stream), "download")
+            self._check(self.lib.mprg_rt_stream_sync(self.stream), "download")
+        return out
+
+    def _host_block(self, nbytes: int) -> _RtHostBuffer:
+        hb = _RtHostBuffer(self._ptr(self.lib.mprg_rt_host_malloc(int(nbytes)), f"page-locked allocation of {nbytes} bytes"), int(nbytes))
+        self._host.append(hb)
+        return hb
+
+    def pinned(self, nbytes: int, key):
+        if not hasattr(self, "_pinned_up"):
+            self._pinned_up = {}
+        hb = self._pinned_up.get(key)
+        if hb is None or hb.nbytes < nbytes:
+            hb = self._pinned_up[key] = self._host_block(max(int(nbytes) + (int(nbytes) >> 3), 1 << 20))
+        return hb, hb.array
+
+    def upload_from(self, pinned_buf, nbytes: int):
+        if nbytes == 0:
+            return self.empty(16)
+        buf = self.empty(nbytes)
+        self._check(self.lib.mprg_rt_memcpy_async(buf.mprg_addr, pinned_buf.mprg_addr, int(nbytes), 1, self.stream), "upload")
+        return buf
+
+    def host_visible(self, nbytes: int):
+        hb = self._host_block(max(int(nbytes), 16))
+        hb.array[:] = 0
+        return hb, hb.array
+
+    def _reap(self):
+        """Drops the buffers whose copies on the copy stream are done."""
+        while self._pending and self.lib.mprg_rt_event_query(self._pending[0][0].h) == 0:
+            self._pending.pop(0)
+
+    def download_async(self, buf, nbytes: int, group: int = 0):
+        """As HipBackend.download_async: copy stream, `async_depth` page-locked buffers per group used in turn."""
+        nbytes = int(nbytes)
+        if not hasattr(self, "_pinned"):
+            self._pinned, self._parity = {}, {}
+            self._copy_stream = self._ptr(self.lib.mprg_rt_stream_create(), "stream")
+        depth = getattr(self, "async_depth", 2)
+        par = self._parity.get(group, 0) % depth
+        self._parity[group] = par + 1
+        host = self._pinned.get((group, par))
+        if host is None or host.nbytes < nbytes:
+            for q in range(depth):
+                if self._pinned.get((group, q)) is None or self._pinned[(group, q)].nbytes < nbytes:
+                    self._pinned[(group, q)] = self._host_block(max(nbytes + (nbytes >> 3), 1 << 20))
+            host = self._pinned[(group, par)]
+        self._reap()
+        ready = _RtEvent(self.lib, False)
+        ready.record(self.stream)
+        self._check(self.lib.mprg_rt_stream_wait_event(self._copy_stream, ready.h), "copy stream")
+        if nbytes:
+            self._check(self.lib.mprg_rt_memcpy_async(host.mprg_addr, self.ptr(buf), nbytes, 2, self._copy_stream), "download")
+        done = _RtEvent(self.lib, False)
+        done.record(self._copy_stream)
+        self._pending.append((done, buf, ready))          # buf must not be handed out again before the copy ran
+        return host.array[:nbytes], done.synchronize
+
+    def ptr(self, buf) -> int:
+        return buf.mprg_addr
+
+    def grown(self, buf, used_bytes: int, new_bytes: int):
+        new = self.empty(int(new_bytes))
+        if used_bytes:
+            self._check(self.lib.mprg_rt_memcpy_async(new.mprg_addr, self.ptr(buf), int(used_bytes), 3, self.stream), "copy")
+        return new
+
+    def synchronize(self):
+        self._check(self.lib.mprg_rt_stream_sync(self.stream), "synchronize")
+
+    def _event_pair(self):
+        return (_RtEvent(self.lib, True), _RtEvent(self.lib, True))
+
+    def _record(self, event, side):
+        event.record(self.stream if side is None else self._side[side])
+
+    n_side_streams = 3
+
+    def _sides(self, n):
+        if not hasattr(self, "_side"):
+            self._side = []
+        while len(self._side) < n:
+            self._side.append(self._ptr(self.lib.mprg_rt_stream_create(), "stream"))
+        return self._side[:n]
+
+    def side_ptr(self, i: int):
+        return self._sides(i + 1)[i]
+
+    def fork(self, n: int):
+        ev = _RtEvent(self.lib, False)
+        ev.record(self.stream)
+        for s_ in self._sides(n):
+            self.lib.mprg_rt_stream_wait_event(s_, ev.h)
+
+    def join(self, n: int):
+        for s_ in self._sides(n):
+            ev = _RtEvent(self.lib, False)
+            ev.record(s_)
+            self.lib.mprg_rt_stream_wait_event(self.stream, ev.h)

@@ -26,6 +26,8 @@ static int check_launch(const char *name) {
   return 0;
 }
 
+#include "runtime_api.inc"
+
 #define BLOCK_VIEW 256
 #include <stdlib.h>
 // workgroup-size knobs of a few kernels (diagnostic runs): read ONCE, when the library is loaded

@@ -1,4 +1,5 @@
 """Process-wide default device backend (lazy): the HIP library + GPU, or an explicit override for tests."""
+import os
 from typing import Optional
 
 _backend = None
@@ -10,11 +11,17 @@ def set_backend(backend) -> None:
     _backend = backend
 
 
-def get_backend():
+def get_backend(kind: Optional[str] = None):
+    """kind: "torch" (HipBackend: torch.cuda buffers and streams; the default) or "runtime" (HipRuntimeBackend: the library's
+    own mprg_rt_* plumbing, no torch import — what the command line's pipeline asks for).  MPRG_BACKEND overrides both."""
     global _backend
     if _backend is None:
-        from .backend import HipBackend
-        _backend = HipBackend()          # raises MprgError without libmprg_hip.so + a ROCm device: no fallback
+        kind = os.environ.get("MPRG_BACKEND") or kind or "torch"
+        if kind not in ("torch", "runtime"):
+            raise ValueError(f"MPRG_BACKEND: torch or runtime, not {kind!r}")
+        from . import backend as b
+        # both raise MprgError without libmprg_hip.so + a ROCm device: no fallback
+        _backend = b.HipRuntimeBackend() if kind == "runtime" else b.HipBackend()
     return _backend
 
 

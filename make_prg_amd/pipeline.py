@@ -31,7 +31,7 @@ from .utils.io_utils import remove_known_input_extensions
 from .utils.zip_stream import StoredZipWriter
 
 logger = logging.getLogger("make_prg_amd")
-CHUNK = int(os.environ.get("MPRG_CHUNK", "4096"))          # alignment files per resident batch
+CHUNK = int(os.environ.get("MPRG_CHUNK", "1536"))          # alignment files per resident batch (profiles/r03/cli/cli_runtime_backend_chunk_sizes.txt)
 DEPTH = 3                                                  # chunks in flight: build | encode | write
 TRACE = os.environ.get("MPRG_PIPELINE_TRACE", "") not in ("", "0")
 # threads that write one container side by side: buffered writes to ONE file take the inode's lock in turn (tools/write_probe.py:

@@ -365,7 +365,7 @@ def _run(options, backend, pool, n_workers):
         # alignments resident on the device, containers written while the next chunk builds); make_prg_amd/pipeline.py
         from ..device import get_backend
         from ..pipeline import run_pipeline
-        n_built = run_pipeline(mine, options, backend or get_backend)
+        n_built = run_pipeline(mine, options, backend or (lambda: get_backend("runtime")))
         logger.info(f"{n_built} of {len(mine)} loci built and written in {time.time() - t0:.1f}s ({max(1, int(getattr(options, 'threads', 1) or 1))} host threads)")
         if n_built == 0:
             logger.error("No PRGs were built, please check errors")

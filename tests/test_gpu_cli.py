@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_command_line_with_host_workers(tmp_path):
+@pytest.mark.parametrize("backend", ["runtime", "torch"])
+def test_command_line_with_host_workers(tmp_path, backend):
     d = tmp_path / "msas"
     d.mkdir()
     want = {}
@@ -23,7 +24,7 @@ def test_command_line_with_host_workers(tmp_path):
         (d / f"gene{seed}.fa").write_text(text)
         want[f"gene{seed}"] = orc.build_locus_from_text(text, 5, 7)[0]
     prefix = tmp_path / "out" / "pan"
-    env = dict(os.environ, PYTHONPATH=ROOT)
+    env = dict(os.environ, PYTHONPATH=ROOT, MPRG_BACKEND=backend)
     res = subprocess.run([sys.executable, "-m", "make_prg_amd", "from_msa", "-i", str(d), "-o", str(prefix), "-t", "3", "-O", "p"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]

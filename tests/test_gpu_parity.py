@@ -8,10 +8,12 @@ from tests import parity_common as pc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def hip():
-    from make_prg_amd.backend import HipBackend
-    return HipBackend(0)          # raises if the library or the GPU is missing: no fallback
+@pytest.fixture(scope="module", params=["torch", "runtime"])
+def hip(request):
+    """Both product backends over the same library: device buffers and streams from torch, or from the library's own
+    mprg_rt_* plumbing (no torch; what the command line uses).  Either raises if the library or the GPU is missing."""
+    from make_prg_amd.backend import HipBackend, HipRuntimeBackend
+    return HipBackend(0) if request.param == "torch" else HipRuntimeBackend(0)
 
 
 def test_library_is_the_hip_build(hip):

@@ -1,0 +1,63 @@
+"""HipRuntimeBackend (make_prg_amd/backend.py: the product backend without torch, over the library's mprg_rt_* calls) driven
+through the CPU emulation build of the same sources: "device" memory is host memory there, so the allocator, the copies, the
+events and the whole recursion forest through this backend are checked in the GPU-less container.  tests/test_gpu_runtime.py
+repeats it on the GPU."""
+import numpy as np
+import pytest
+
+from make_prg_amd.backend import HipRuntimeBackend
+from tests import parity_common as pc
+from tests.emu.backend import build_emu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    return HipRuntimeBackend(lib_path=build_emu())
+
+
+def test_size_classes_and_reuse(rt):
+    caps = [rt._capacity(n) for n in (1, 512, 513, 4096, 5000, 1 << 20, (1 << 20) + 1, 3 << 30)]
+    assert caps[0] == 512 and caps[1] == 512 and caps[2] == 1024
+    for n, c in zip((1, 512, 513, 4096, 5000, 1 << 20, (1 << 20) + 1, 3 << 30), caps):
+        assert c >= n and (c - n) <= max(512, n // 8 + 1)
+    a = rt.empty(5000)
+    addr = a.mprg_addr
+    del a
+    b = rt.empty(4700)                     # same size class: the block comes back
+    assert b.mprg_addr == addr and len(b) == 4700
+    z = rt.zeros(1000)
+    assert not rt.download(z, np.uint8, 1000).any()
+
+
+def test_copies_and_events(rt):
+    x = np.arange(100000, dtype=np.int64)
+    d = rt.upload(x)
+    assert np.array_equal(rt.download(d, np.int64, x.size), x)
+    g = rt.grown(d, x.nbytes, 2 * x.nbytes)
+    assert np.array_equal(rt.download(g, np.int64, x.size), x)
+    hb, arr = rt.pinned(1 << 16, "k")
+    arr[:1000] = 7
+    d2 = rt.upload_from(hb, 1000)
+    assert (rt.download(d2, np.uint8, 1000) == 7).all()
+    assert rt.pinned(100, "k")[0] is hb                      # kept per key
+    hv, harr = rt.host_visible(96 * 8)
+    assert harr.size == 96 * 8 and not harr.any() and rt.ptr(hv) == harr.ctypes.data
+    rt.async_depth = 2
+    outs = []
+    for r in range(3):                                       # two buffers used in turn
+        got, wait = rt.download_async(d, 8000, group=5)
+        wait()
+        outs.append(got.ctypes.data)
+        assert np.array_equal(got.view(np.int64), x[:1000])
+    assert outs[0] == outs[2] != outs[1]
+    e0, e1 = rt._event_pair()
+    rt._record(e0, None)
+    rt._record(e1, None)
+    assert e0.elapsed_time(e1) >= 0.0
+    rt.trim()
+    assert rt._free == {}
+
+
+def test_forest_through_the_runtime_backend(rt, golden_integration, golden_synthetic):
+    assert pc.check_integration(rt, golden_integration) >= 30
+    assert pc.check_synthetic(rt, golden_synthetic, configs=("B",), limit=6) == 6
