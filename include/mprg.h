@@ -74,6 +74,14 @@ int mprg_column_residue_counts(const uint8_t *raw, const int64_t *table, const i
 int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int32_t *work,
                       int n_items, int rows_per_chunk, uint32_t *out_mask, void *stream);
 
+/* A8 — utils/seq_utils.py:193-216 (remove_columns_full_of_gaps_from_MSA; recursion_tree.py:45 stores the result as
+ * node.alignment).  The all-gap columns of each view (mask == 1 << MPRG_CODE_GAP, from mprg_column_masks) are dropped, the rest
+ * written as a dense n_rows x kept[view] matrix of cell codes, row-major, at out + out_off[view] (the caller lays `out` out for
+ * n_rows x n_cols per view: kept is only known afterwards).  work: n_items x 2 int32 {view, row chunk}; rows_per_chunk rows per
+ * item; kept: int32 per view. */
+int mprg_compact_columns(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int32_t *work, int n_items,
+                         int rows_per_chunk, const uint32_t *mask, uint8_t *out, const int64_t *out_off, int32_t *kept, void *stream);
+
 /* A3-A6 — from_msa/interval_partition.py:81-252 (IntervalPartitioner) with utils/seq_utils.py:37-42
  * (has_empty_sequence) and the <2-sequences test of :187-217.  Gap runs: one workgroup per (view, 256-row chunk)
  * — work_rows: n x 2 int32 {view, chunk} —; the interval scan itself: one workgroup per view.

@@ -79,6 +79,14 @@ int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t 
   return check_launch("k_column_masks");
 }
 
+int mprg_compact_columns(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int32_t *work, int n_items,
+                         int rows_per_chunk, const uint32_t *mask, uint8_t *out, const int64_t *out_off, int32_t *kept, void *stream) {
+  if (n_items <= 0) return 0;
+  if (rows_per_chunk <= 0) return fail("rows_per_chunk must be positive");
+  LAUNCH(k_compact_columns, n_items, CC_THREADS, stream, arena, views, rowidx, work, rows_per_chunk, mask, out, out_off, kept);
+  return check_launch("k_compact_columns");
+}
+
 int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
                    const uint32_t *mask, int min_match_length, const int32_t *work_rows, int n_work_rows,
                    uint32_t *maxrun, int32_t *stack, int32_t *ivflag, int32_t *iv, int32_t *n_iv, int32_t *status,

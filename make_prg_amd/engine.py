@@ -834,6 +834,25 @@ def _bm_column_masks(self: BatchEngine, alignment: MSA) -> np.ndarray:
     return be.download(d_mask, np.uint32, total_cols)
 
 
+def _bm_compact_columns(self: BatchEngine, alignment: MSA) -> np.ndarray:
+    """The alignment's cell codes without its all-gap columns (A8), by mprg_column_masks + mprg_compact_columns."""
+    eng, nodes = _one_view_engine(self.be, alignment)
+    tab, rowidx, total_cols, _ = eng._view_table(nodes, [0])
+    be = eng.be
+    S, C = int(tab[0, 5]), int(tab[0, 7])
+    d_views, d_rowidx = be.upload(tab), be.upload(rowidx)
+    work, rpc = eng._mask_work(tab)
+    d_work, d_mask = be.upload(work), be.zeros(4 * total_cols)
+    be.call("mprg_column_masks", be.ptr(eng.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_work), work.shape[0],
+            rpc, be.ptr(d_mask), be.stream)
+    wr = eng._row_chunk_work(tab, 64)
+    d_wr, d_out, d_off, d_kept = be.upload(wr), be.empty(S * C), be.upload(np.zeros(1, np.int64)), be.zeros(4)
+    be.call("mprg_compact_columns", be.ptr(eng.d_arena), be.ptr(d_views), be.ptr(d_rowidx), be.ptr(d_wr), len(wr), 64,
+            be.ptr(d_mask), be.ptr(d_out), be.ptr(d_off), be.ptr(d_kept), be.stream)
+    kept = int(be.download(d_kept, np.int32, 1)[0])
+    return be.download(d_out, np.uint8, S * kept).reshape(S, kept)
+
+
 def _bm_partition(self: BatchEngine, alignment: MSA, L: int, consensus: Optional[str] = None):
     """IntervalPartitioner on one alignment.  With `consensus` given, the partition follows THAT string (the
     reference's constructor takes it as an argument); '*' columns are non-match, anything else match."""
@@ -965,6 +984,7 @@ def _bm_not_one_reference_like(self: BatchEngine, clusters: List[List[str]]) -> 
 
 BatchEngine.some_cluster_not_one_reference_like = _bm_not_one_reference_like
 BatchEngine.column_masks = _bm_column_masks
+BatchEngine.compact_columns = _bm_compact_columns
 BatchEngine.partition = _bm_partition
 BatchEngine.row_groups = _bm_row_groups
 BatchEngine.cluster = _bm_cluster

@@ -594,32 +594,67 @@ ForestEngine.site_count = property(_site_count)
 ForestEngine.tree_sizes = property(lambda self: np.where(self.root_of >= 0, self.asm[np.maximum(self.root_of, 0), A_SIZE], 0))
 
 
+def forest_stored_alignments(self: ForestEngine, node_idx: np.ndarray) -> List[np.ndarray]:
+    """node.alignment of the listed nodes as cell codes: the node's rows x columns without the columns that hold only gaps
+    (recursion_tree.py:45 -> utils/seq_utils.py:193-216), compacted ON THE DEVICE: mprg_column_masks over the nodes' views,
+    then mprg_compact_columns (A8); one download of the dense matrices."""
+    be, t = self.be, self.tab
+    node_idx = np.asarray(node_idx, np.int64)
+    n = len(node_idx)
+    if n == 0:
+        return []
+    meta = self.meta_arr[t["msa"][node_idx]]
+    S, C = t["nrows"][node_idx], t["ncols"][node_idx]
+    tab = np.zeros((n, VF), np.int64)
+    tab[:, 0:4] = meta[:, 0:4]
+    tab[:, 4], tab[:, 5], tab[:, 6], tab[:, 7] = t["rows_off"][node_idx], S, t["col0"][node_idx], C
+    tab[:, 8], tab[:, 9] = np.cumsum(C) - C, np.cumsum(S) - S
+    total_cols = int(C.sum())
+    out_off = np.cumsum(S * C) - S * C
+    out_bytes = int((S * C).sum())
+    d_views = be.upload(tab)
+    work, rpc = self._mask_work(tab)
+    d_work, d_mask = be.upload(work), be.zeros(4 * max(total_cols, 1))
+    cells = float((S * C).sum())
+    be.call("mprg_column_masks", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(self.d_pool), be.ptr(d_work), work.shape[0], rpc,
+            be.ptr(d_mask), be.stream, work=cells)
+    chunk = 64
+    wr = self._row_chunk_work(tab, chunk)
+    d_wr, d_out, d_off, d_kept = be.upload(wr), be.empty(max(out_bytes, 16)), be.upload(out_off), be.zeros(4 * n)
+    be.call("mprg_compact_columns", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(self.d_pool), be.ptr(d_wr), len(wr), chunk,
+            be.ptr(d_mask), be.ptr(d_out), be.ptr(d_off), be.ptr(d_kept), be.stream, work=2 * cells)
+    kept = be.download(d_kept, np.int32, n)
+    dense = be.download(d_out, np.uint8, out_bytes)
+    return [dense[o:o + s_ * k].reshape(s_, k) for o, s_, k in zip(out_off.tolist(), S.tolist(), kept.tolist())]
+
+
 def forest_tree_dump(self: ForestEngine, mi: int, ids: List[str]) -> list:
     """Preorder dump of one tree (same shape as oracle.from_msa_oracle.tree_dump); requires assemble_prgs() first."""
     t = self.tab
     node_id = self.node_id
-    codes = self.codes[mi]
     kinds = {KIND_LEAF: "leaf", KIND_INTERVAL: "interval", KIND_CLUSTER: "cluster"}
     if getattr(self, "_pool_cache_used", -1) != self.pool_used:
         self._pool_cache, self._pool_cache_used = self.pool_host(), self.pool_used
     pool = self._pool_cache
-    out = []
+    order = []
     stack = [int(self.root_of[mi])]
     while stack:
         ni = stack.pop()
+        order.append(ni)
+        stack.extend(reversed([int(t["first_child"][ni]) + j for j in range(int(t["n_child"][ni]))]))
+    blocks = self.stored_alignments(np.asarray(order))          # all-gap columns are not stored (recursion_tree.py:45)
+    n_rows_msa = int(self.meta_arr[mi, 4])
+    out = []
+    for ni, block in zip(order, blocks):
         rows = self.node_rows(ni, pool)
         if rows is None:
-            rows = np.arange(codes.shape[0])
-        c0, w = int(t["col0"][ni]), int(t["ncols"][ni])
-        block = codes[rows, c0:c0 + w]
-        block = decode(block[:, ~(block == CODE_GAP).all(axis=0)])      # all-gap columns are not stored (recursion_tree.py:45)
+            rows = np.arange(n_rows_msa)
         kids = [int(t["first_child"][ni]) + j for j in range(int(t["n_child"][ni]))]
         par = int(t["parent"][ni])
         out.append(dict(id=int(node_id[ni]), kind=kinds[int(t["kind"][ni])], level=int(t["level"][ni]),
                         parent=None if par < 0 else int(node_id[par]),
-                        rows=[[ids[r], b.tobytes().decode()] for r, b in zip(rows, block)],
+                        rows=[[ids[r], b.tobytes().decode()] for r, b in zip(rows, decode(block))],
                         children=[int(node_id[c]) for c in kids]))
-        stack.extend(reversed(kids))
     return out
 
 
@@ -638,6 +673,7 @@ def forest_prg_index(self: ForestEngine, mi: int) -> list:
 
 
 ForestEngine.prg_index_entries = forest_prg_index_entries
+ForestEngine.stored_alignments = forest_stored_alignments
 ForestEngine.tree_dump = forest_tree_dump
 ForestEngine.prg_index = forest_prg_index
 

@@ -305,9 +305,14 @@ def unpack_records(buf) -> Dict[str, dict]:
     return out
 
 
+GATHER_ROUND_BYTES = int(os.environ.get("MPRG_GATHER_ROUND_BYTES", str(1 << 30)))
+
+
 def gather_records(local: Dict[str, dict], dist, rank: int, world: int):
-    """all_gather of the ranks' byte counts, then ONE gather of the packed records, padded to the largest, as uint8 (RCCL
-    moves device tensors; gloo host tensors).  Returns the merged dictionary on rank 0, None elsewhere."""
+    """all_gather of the ranks' byte counts, then the packed records gathered on rank 0 as uint8 in ROUNDS of at most
+    GATHER_ROUND_BYTES per rank (RCCL moves device tensors; gloo host tensors): rank 0 holds world x one round on the device,
+    never world x the largest payload, and no single collective comes near 2^31 bytes.  Returns the merged dictionary on rank 0,
+    None elsewhere."""
     import torch
     on_device = dist.get_backend() == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
@@ -316,16 +321,27 @@ def gather_records(local: Dict[str, dict], dist, rank: int, world: int):
     dist.all_gather(sizes, torch.tensor([payload.size], dtype=torch.int64, device=dev))
     sizes = [int(t.item()) for t in sizes]
     cap = max(max(sizes), 1)
-    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    if payload.size:
-        mine[:payload.size] = torch.from_numpy(payload.copy()).to(dev)
-    parts = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-    dist.gather(mine, parts, dst=0)
+    host = [np.empty(n, np.uint8) for n in sizes] if rank == 0 else None
+    for lo in range(0, cap, GATHER_ROUND_BYTES):
+        n = min(GATHER_ROUND_BYTES, cap - lo)
+        mine = torch.zeros(n, dtype=torch.uint8, device=dev)
+        seg = payload[lo:lo + n]
+        if seg.size:
+            mine[:seg.size] = torch.from_numpy(seg.copy()).to(dev)
+        parts = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, parts, dst=0)
+        if rank == 0:
+            for r, t in enumerate(parts):
+                take = max(0, min(sizes[r] - lo, n))
+                if take:
+                    host[r][lo:lo + take] = t[:take].cpu().numpy()
+        del parts, mine
     if rank != 0:
         return None
     merged: Dict[str, dict] = {}
-    for t, n in zip(parts, sizes):
-        merged.update(unpack_records(t[:n].cpu().numpy().tobytes()))
+    for r in range(world):
+        merged.update(unpack_records(host[r]))          # fields are copied out of a memoryview of the array, one by one
+        host[r] = None                                  # ... and the rank's payload is released before the next one
     return merged
 
 

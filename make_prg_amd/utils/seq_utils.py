@@ -91,15 +91,20 @@ def _consensus_host_rare(alignment: MSA) -> str:
 
 
 def remove_columns_full_of_gaps_from_MSA(alignment: MSA) -> MSA:
-    """reference utils/seq_utils.py:193-216; the all-gap column mask comes from the device."""
+    """reference utils/seq_utils.py:193-216, on the device (mprg_column_masks + mprg_compact_columns).  Bytes outside the
+    kernels' alphabet (the reference drops all-gap columns of any text) and lower case (the cell codes fold it) keep the
+    host's own column selection."""
     if len(alignment) == 0 or alignment.get_alignment_length() == 0:
         return alignment
     codes = encode(alignment.data)
     if (codes == 255).any():
         keep = ~(alignment.data == ord(GAP)).all(axis=0)
-    else:
+        return MSA(_data=alignment.data[:, keep], _ids=alignment.ids, _descs=alignment.descriptions)
+    if not np.array_equal(decode(codes), alignment.data):
         keep = _masks_of(alignment) != _eng.BIT_GAP
-    return MSA(_data=alignment.data[:, keep], _ids=alignment.ids, _descs=alignment.descriptions)
+        return MSA(_data=alignment.data[:, keep], _ids=alignment.ids, _descs=alignment.descriptions)
+    dense = _eng.BatchEngine(get_backend(), 1, 1).compact_columns(alignment)
+    return MSA(_data=decode(dense), _ids=alignment.ids, _descs=alignment.descriptions)
 
 
 def has_empty_sequence(alignment: MSA, interval: Tuple[int, int]) -> bool:

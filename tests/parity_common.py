@@ -117,3 +117,29 @@ def check_vs_oracle(backend, texts, N=5, L=7):
         assert g["tree"] == orc.tree_dump(root)
         assert g["prg_index"] == sorted([s, e, n] for (s, e), n in b.prg_index.items())
     return eng
+
+
+def check_compact_columns(backend) -> int:
+    """mprg_compact_columns (A8) behind remove_columns_full_of_gaps_from_MSA against NumPy: narrow, wide (places in LDS) and
+    very wide (places recomputed per tile) alignments, all-gap runs at the edges, nothing to drop, everything dropped."""
+    from make_prg_amd import device
+    from make_prg_amd.msa import MSA
+    from make_prg_amd.utils import seq_utils as su
+    rng = np.random.default_rng(11)
+    device.set_backend(backend)
+    n = 0
+    try:
+        for rows, cols, p_gapcol in ((3, 17, 0.3), (70, 700, 0.5), (130, 3000, 0.1), (5, 9000, 0.4), (4, 50, 0.0), (4, 50, 1.0)):
+            data = rng.choice(np.frombuffer(b"ACGT-", np.uint8), size=(rows, cols), p=[0.22, 0.22, 0.22, 0.22, 0.12])
+            drop = rng.random(cols) < p_gapcol
+            data[:, drop] = ord("-")
+            data[:, :2] = ord("-")
+            msa = MSA.from_strings([r.tobytes().decode() for r in data])
+            got = su.remove_columns_full_of_gaps_from_MSA(msa)
+            want = data[:, ~(data == ord("-")).all(axis=0)]
+            assert got.get_alignment_length() == want.shape[1]
+            assert np.array_equal(got.data, want)
+            n += 1
+    finally:
+        device.set_backend(None)
+    return n

@@ -58,3 +58,8 @@ def test_load_time_consensus_counts_from_the_device(emu):
 def test_kmer_sizes_above_16(emu):
     from tests.long_kmer_common import check_long_kmers
     assert check_long_kmers(emu) == 4
+
+
+def test_compact_columns_matches_numpy(emu):
+    """mprg_compact_columns (A8) behind remove_columns_full_of_gaps_from_MSA (tests/parity_common.py)."""
+    assert pc.check_compact_columns(emu) == 6

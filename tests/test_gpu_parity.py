@@ -33,6 +33,11 @@ def test_synthetic_config_c_and_deep(hip, golden_synthetic):
     assert pc.check_synthetic(hip, golden_synthetic, configs=("C", "Dsmall")) == 7
 
 
+def test_compact_columns(hip):
+    """A8 on the device (mprg_compact_columns); the tree dumps of the tests above go through it too (node.alignment)."""
+    assert pc.check_compact_columns(hip) == 6
+
+
 def test_kmeans_known_answers(hip, golden_kmeans):
     """The device KMeans against the scikit-learn answers captured from the reference run (labels, inertia bits)."""
     from tests.kmeans_direct import run_kmeans_fits
