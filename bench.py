@@ -137,7 +137,7 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None):
     try:
         from concurrent.futures import ThreadPoolExecutor
         import numpy as np
-        from make_prg_amd.backend import HipBackend
+        from make_prg_amd.backend import make_backend
         from make_prg_amd.forest import ForestEngine
         texts, msas = make_batch(seeds, gen_procs)      # forks (if at all) before this process touches the GPU
         if cli_dir:                                     # the command-line leg reads the same alignments as FASTA files
@@ -145,7 +145,8 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None):
                 with open(os.path.join(cli_dir, f"gene{sd:05d}.fa"), "w") as fh:
                     fh.write(t)
         n_streams = max(1, min(n_streams, len(msas)))
-        bes = [HipBackend(device, own_stream=True) for _ in range(n_streams)]
+        # buffers, streams and events from the library's own mprg_rt_* plumbing (MPRG_BACKEND=torch: from torch.cuda); same kernels
+        bes = [make_backend(None, device, own_stream=True) for _ in range(n_streams)]
         engs = [ForestEngine(b, max_nesting=5, min_match_length=7) for b in bes]
         t_ing = time.perf_counter()
         for i, (e, b) in enumerate(zip(engs, bes)):      # ingest: encode + upload; inputs are now resident in HBM

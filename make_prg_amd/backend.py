@@ -545,3 +545,11 @@ class HipRuntimeBackend(_Base):
             ev = _RtEvent(self.lib, False)
             ev.record(s_)
             self.lib.mprg_rt_stream_wait_event(self.stream, ev.h)
+
+
+def make_backend(kind: Optional[str] = None, device: Optional[int] = None, own_stream: bool = True):
+    """A product backend by name: "torch" (HipBackend) or "runtime" (HipRuntimeBackend); None: MPRG_BACKEND, else "runtime"."""
+    kind = kind or os.environ.get("MPRG_BACKEND") or "runtime"
+    if kind not in ("torch", "runtime"):
+        raise ValueError(f"backend: torch or runtime, not {kind!r}")
+    return HipRuntimeBackend(device) if kind == "runtime" else HipBackend(device, own_stream=own_stream)

@@ -1,7 +1,7 @@
 """HipRuntimeBackend (make_prg_amd/backend.py: the product backend without torch, over the library's mprg_rt_* calls) driven
 through the CPU emulation build of the same sources: "device" memory is host memory there, so the allocator, the copies, the
-events and the whole recursion forest through this backend are checked in the GPU-less container.  tests/test_gpu_runtime.py
-repeats it on the GPU."""
+events and the whole recursion forest through this backend are checked in the GPU-less container.  On the GPU,
+tests/test_gpu_parity.py runs every case through both product backends."""
 import numpy as np
 import pytest
 

@@ -6,13 +6,13 @@ import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bench import make_batch
-from make_prg_amd.backend import HipBackend
+from make_prg_amd.backend import HipBackend, HipRuntimeBackend
 from make_prg_amd.forest import ForestEngine
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 texts, msas = make_batch(list(range(batch)), 16)
-be = HipBackend(0)
+be = HipRuntimeBackend(0) if os.environ.get('MPRG_BACKEND') == 'runtime' else HipBackend(0)
 eng = ForestEngine(be, 5, 7)
 eng.load(msas)
 be.synchronize()
