@@ -130,7 +130,7 @@ def source_digest():
     return h.hexdigest()[:16]
 
 
-def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None):
+def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None, backend_kind=None):
     """One host worker process: owns `n_streams` engines (HIP streams, one host thread each) on GPU `device` and a share
     of the rank's alignments.  The reference's own parallelism is a process pool over MSAs (from_msa `-t`); here the
     processes feed one GPU so that the array-at-a-time host control of several sub-batches overlaps."""
@@ -146,7 +146,7 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None):
                     fh.write(t)
         n_streams = max(1, min(n_streams, len(msas)))
         # buffers, streams and events from the library's own mprg_rt_* plumbing (MPRG_BACKEND=torch: from torch.cuda); same kernels
-        bes = [make_backend(None, device, own_stream=True) for _ in range(n_streams)]
+        bes = [make_backend(backend_kind, device, own_stream=True) for _ in range(n_streams)]
         engs = [ForestEngine(b, max_nesting=5, min_match_length=7) for b in bes]
         t_ing = time.perf_counter()
         for i, (e, b) in enumerate(zip(engs, bes)):      # ingest: encode + upload; inputs are now resident in HBM
@@ -359,7 +359,8 @@ def main():
     if W == 0:          # --workers 0: the same worker loop on a thread of this process (rocprofv3 runs: nothing forks)
         import threading
         a, b = ctx.Pipe()
-        th = threading.Thread(target=_worker, args=(b, local_rank, seeds, args.streams), daemon=True)
+        # (this process also runs torch: its worker thread takes its buffers and streams from torch too — one HIP runtime per process)
+        th = threading.Thread(target=_worker, args=(b, local_rank, seeds, args.streams, 1, None, "torch"), daemon=True)
         th.start()
         conns.append(a)
 
@@ -420,11 +421,11 @@ def main():
     counters = {k_: sum(c_[k_] for _, c_, _ in reports) for k_ in reports[0][1]}
     counters["levels"] = max(c_["levels"] for _, c_, _ in reports)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=device if dist_backend == "nccl" else "cpu")
+    t = torch.tensor([dt], dtype=torch.float64, device=device if (dist_backend == "nccl" and world > 1) else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
-    n_local = torch.tensor([len(seeds)], dtype=torch.float64, device=device if dist_backend == "nccl" else "cpu")
+    n_local = torch.tensor([len(seeds)], dtype=torch.float64, device=device if (dist_backend == "nccl" and world > 1) else "cpu")
     if world > 1:
         dist.all_reduce(n_local, op=dist.ReduceOp.SUM)
     msas_per_step = int(n_local.item())          # strong: --batch; weak: --batch x ranks
@@ -440,7 +441,7 @@ def main():
                         against="tests/golden/config_c_digests.bin (oracle: sha256(PRG)[:8] + node count per seed)")
     if world > 1:
         flag = torch.tensor([0 if verified is None else verified["mismatches"]], dtype=torch.float64,
-                            device=device if dist_backend == "nccl" else "cpu")
+                            device=device if (dist_backend == "nccl" and world > 1) else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.SUM)
         if verified is not None:
             verified["mismatches_all_ranks"] = int(flag.item())
@@ -527,7 +528,7 @@ def main():
 
     # whole-job counters (strong scaling: a rank's workers only saw its shard)
     keys = ("launches", "fits", "cells_all", "cells_clustered", "kmeans_bytes", "syncs")
-    cvec = torch.tensor([float(counters.get(k_, 0)) for k_ in keys], dtype=torch.float64, device=device if dist_backend == "nccl" else "cpu")
+    cvec = torch.tensor([float(counters.get(k_, 0)) for k_ in keys], dtype=torch.float64, device=device if (dist_backend == "nccl" and world > 1) else "cpu")
     if world > 1:
         dist.all_reduce(cvec, op=dist.ReduceOp.SUM)
     for k_, v_ in zip(keys, cvec.tolist()):
