@@ -33,3 +33,46 @@ def test_command_line_with_host_workers(tmp_path, backend):
     for name, prg in zip(lines[0::2], lines[1::2]):
         got[name[1:]] = prg
     assert got == want
+
+
+def test_streamed_pipeline_equals_the_object_path_on_the_gpu(tmp_path):
+    """`-O a` through the streamed pipeline (several chunks, runtime backend, native threads) and through the per-locus object
+    path on the same directory — a gzipped file and a file with duplicate row ids among them: same .prg.fa bytes, same zip
+    members (CRCs checked), equal builders in update_DS.zip."""
+    import gzip
+    import zipfile
+    from make_prg_amd.prg_builder import PrgBuilderZipDatabase
+    d = tmp_path / "msas"
+    d.mkdir()
+    for seed in range(700, 716):
+        text = synth_config_fasta("B", seed)
+        if seed % 5 == 1:
+            with gzip.open(d / f"gene{seed}.fa.gz", "wt") as fh:
+                fh.write(text)
+        else:
+            (d / f"gene{seed}.fa").write_text(text)
+    (d / "dup_ids.fa").write_text(">a\nACGTACGTACGTTTTT\n>a\nACGTACGAACGTTTTT\n>b\nACGTACGTACGTATTT\n")
+    outs = {}
+    for mode in ("1", "0"):
+        prefix = tmp_path / f"out{mode}" / "pan"
+        env = dict(os.environ, PYTHONPATH=ROOT, MPRG_PIPELINE=mode, MPRG_CHUNK="5")
+        res = subprocess.run([sys.executable, "-m", "make_prg_amd", "from_msa", "-i", str(d), "-o", str(prefix), "-t", "4", "-O", "a"],
+                             cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-2000:]
+        files = {p.name: p for p in (tmp_path / f"out{mode}").iterdir()}
+        assert sorted(files) == ["pan.prg.bin.zip", "pan.prg.fa", "pan.prg.gfa.zip", "pan.update_DS.zip"]
+        got = {"fa": files["pan.prg.fa"].read_bytes()}
+        for kind in ("bin", "gfa"):
+            with zipfile.ZipFile(files[f"pan.prg.{kind}.zip"]) as z:
+                assert z.testzip() is None
+                got[kind] = {m: z.read(m) for m in sorted(z.namelist())}
+        db = PrgBuilderZipDatabase(files["pan.update_DS.zip"])
+        db.load()
+        got["builders"] = {l: db.get_PrgBuilder(l) for l in db.get_loci_names()}
+        db.close()
+        outs[mode] = got
+    a, b = outs["1"], outs["0"]
+    assert a["fa"] == b["fa"] and a["bin"] == b["bin"] and a["gfa"] == b["gfa"]
+    assert sorted(a["builders"]) == sorted(b["builders"]) and len(a["builders"]) == 17
+    for l in a["builders"]:
+        assert a["builders"][l].build_prg() == b["builders"][l].build_prg(), l
