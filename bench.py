@@ -17,8 +17,9 @@ What the one JSON line holds (rank 0):
   roofline         from an untimed EXCLUSIVE pass: worker 0 alone on the device, one stream, its own sub-batch, HIP events
                    around every entry point (so the kernels' times add up to less than that pass's wall time); dominant
                    kernel + the top kernels with their fraction of the HBM roofline
-  end_to_end       (N=1) FASTA text in memory -> parsed, encoded, uploaded, built, PRG + .bin + .gfa bytes in memory, all
-                   workers in parallel; the CPU baseline below covers the identical region
+  end_to_end       (N=1) FASTA bytes in memory -> parsed (native batch parser), uploaded, built, PRG + .bin + .gfa bytes in memory
+                   (native batch encoders), all workers in parallel: the command line's stages without its files; the CPU
+                   baseline's end_to_end_value covers the identical region
   cpu_baseline     (N=1) the oracle (CPU restatement of the reference path, `port`) on a bounded sample, all host cores
 
 Defaults: K = 10 timed steps after W = 2 warm-up steps.  The workers run their steps back to back without a barrier in
@@ -140,6 +141,8 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None, backend_k
         from make_prg_amd.backend import make_backend
         from make_prg_amd.forest import ForestEngine
         texts, msas = make_batch(seeds, gen_procs)      # forks (if at all) before this process touches the GPU
+        texts_b = [t.encode() for t in texts]           # the end-to-end leg starts from the bytes a file would hold
+        e2e_threads = max(1, gen_procs)                 # threads of the native batch stages in that leg (CPUs / workers)
         if cli_dir:                                     # the command-line leg reads the same alignments as FASTA files
             for sd, t in zip(seeds, texts):
                 with open(os.path.join(cli_dir, f"gene{sd:05d}.fa"), "w") as fh:
@@ -174,35 +177,50 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None, backend_k
             return n_ok, chars
 
         def end_to_end():
-            """FASTA text -> PRG, .bin and .gfa bytes, nothing resident beforehand (a fresh engine; stream 0)."""
-            from make_prg_amd.msa import load_alignment_text
+            """FASTA text (bytes in memory) -> PRG, .bin and .gfa bytes in memory, nothing resident beforehand: the stages of the
+            command line's pipeline (make_prg_amd/pipeline.py) without its files — libmprg's batch parser into a pinned arena,
+            one upload, the forest and the PRG text on the device, every locus encoded once by the batch encoders; the natives
+            run `e2e_threads` threads per worker."""
+            import ctypes
             from make_prg_amd.utils import native
-            from make_prg_amd.utils.gfa import GFA_Output
-            from make_prg_amd.utils.prg_encoder import PrgEncoder
+            lib = native.library()
+            n = len(texts_b)
             t0 = time.perf_counter()
-            parsed = [load_alignment_text(t, defer_n=True) for t in texts]
+            ptrs = (ctypes.c_char_p * n)(*texts_b)
+            lens = np.fromiter((len(t) for t in texts_b), np.int64, n)
+            h = lib.mprg_ingest_open_mem_host(ptrs, lens.ctypes.data, n, e2e_threads)
+            info = np.zeros((n, 5), np.int64)
+            lib.mprg_ingest_info_host(h, info.ctypes.data)
+            status, rows, cols, tbytes, flags = (info[:, k] for k in range(5))
+            assert not status.any() and not (flags & 1).any(), "synthetic alignments are plain FASTA with distinct ids"
+            sizes = rows * cols
+            raw_off, t_off = np.cumsum(sizes) - sizes, np.cumsum(tbytes) - tbytes
+            be = bes[0]
+            arena_buf, arena = be.pinned(int(sizes.sum()), "e2e")
+            titles = np.empty(max(int(tbytes.sum()), 1), np.uint8)
+            lib.mprg_ingest_fill_host(h, arena.ctypes.data, raw_off.ctypes.data, titles.ctypes.data, t_off.ctypes.data, e2e_threads)
             t1 = time.perf_counter()
-            with bes[0].on_stream():
-                eng = ForestEngine(bes[0], max_nesting=5, min_match_length=7)
-                eng.load(parsed)
+            with be.on_stream():
+                eng = ForestEngine(be, max_nesting=5, min_match_length=7)
+                eng.load_raw(arena_buf, arena, raw_off, rows, cols, has_n=(flags & 2) != 0)
                 t2 = time.perf_counter()
                 eng.run_forest()
-                prgs = eng.assemble_prgs(as_bytes=True)
+                fin = eng.assemble_prgs(as_bytes=True, lazy=True)
+                fin()
             t3 = time.perf_counter()
-            n_bytes = 0
-            for p in prgs:
-                if p is None:
-                    continue
-                b = bytes(p)
-                arr = native.prg_encode(b)                      # libmprg's one-pass host encoders; the reference-shaped
-                if arr is None:                                 # Python forms take over for strings they do not cover
-                    arr = np.asarray(PrgEncoder().encode(b.decode()), dtype="<u4")
-                g = native.gfa_text(b)
-                if g is None:
-                    g = GFA_Output.gfa_text(b.decode()).encode()
-                n_bytes += arr.nbytes + len(g)
+            length, base = np.ascontiguousarray(fin.length, np.int64), np.ascontiguousarray(fin.base, np.int64)
+            whole = np.frombuffer(fin.buffer, np.uint8)
+            ba, bw, ga, gb = (np.zeros(n, np.int64) for _ in range(4))
+            crc = np.zeros((n, 3), np.uint32)
+            pool_ = lib.mprg_encode_pool_new_host()
+            rc = lib.mprg_encode_batch_host(pool_, whole.ctypes.data, base.ctypes.data, length.ctypes.data, n, e2e_threads, 1, 1,
+                                            ba.ctypes.data, bw.ctypes.data, ga.ctypes.data, gb.ctypes.data, crc.ctypes.data)
+            assert rc == 0 and (bw[length >= 0] >= 0).all() and (gb[length >= 0] >= 0).all()
+            n_bytes = int(4 * bw[bw > 0].sum() + gb[gb > 0].sum())
             t4 = time.perf_counter()
-            return dict(n=sum(p is not None for p in prgs), parse_s=t1 - t0, encode_upload_s=t2 - t1, build_s=t3 - t2,
+            lib.mprg_encode_pool_free_host(pool_)
+            lib.mprg_ingest_close_host(h)
+            return dict(n=int((length >= 0).sum()), parse_s=t1 - t0, encode_upload_s=t2 - t1, build_s=t3 - t2,
                         encoders_s=t4 - t3, out_bytes=n_bytes)
 
         def verify():
@@ -459,8 +477,10 @@ def main():
         parts = command("e2e")
         e2e_s = time.perf_counter() - t0
         e2e = dict(value=round(sum(p["n"] for p in parts) / e2e_s, 3), unit="MSAs/s", seconds=round(e2e_s, 3),
-                   region="FASTA text in memory -> parse (upper-case, N consensus) -> encode + upload -> recursion forest + PRG "
-                          "strings on the device -> .bin (uint32 stream) and .gfa text in memory; all workers in parallel",
+                   region="FASTA bytes in memory -> libmprg's batch parser into a pinned arena (parse_s) -> one upload + device ingest "
+                          "(encode_upload_s) -> recursion forest + PRG text on the device, copied back (build_s) -> every locus's .bin "
+                          "(uint32 stream) and .gfa text + CRC-32s by the batch encoders (encoders_s); the command line's stages without "
+                          "its files; all workers in parallel, native stages with CPUs / workers threads each",
                    max_over_workers_s={k_: round(max(p[k_] for p in parts), 3) for k_ in
                                        ("parse_s", "encode_upload_s", "build_s", "encoders_s")},
                    output_bytes=sum(p["out_bytes"] for p in parts))

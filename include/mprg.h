@@ -399,6 +399,8 @@ long long mprg_fasta_fill_host(const char *text, long long n, uint8_t *matrix, l
 enum { MPRG_INGEST_UNREADABLE_FILE = -6, MPRG_INGEST_NO_RECORDS_FILE = -7 };
 enum { MPRG_INGEST_FLAG_DUP_IDS = 1, MPRG_INGEST_FLAG_HAS_N = 2 };
 void *mprg_ingest_open_host(const char *paths, long long n_files, int n_threads);
+/* the same on texts that are already in memory (text i = lens[i] bytes at texts[i]; not copied: keep them until _close) */
+void *mprg_ingest_open_mem_host(const char *const *texts, const long long *lens, long long n_texts, int n_threads);
 void mprg_ingest_info_host(void *handle, long long *info);
 void mprg_ingest_fill_host(void *handle, uint8_t *arena, const long long *raw_off, char *titles, const long long *title_off,
                            int n_threads);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "mprg_fasta_fill_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong, c_void_p]),
     "mprg_gfa_text_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p, ctypes.c_longlong]),
     "mprg_ingest_open_host": (c_void_p, [c_void_p, ctypes.c_longlong, c_int]),
+    "mprg_ingest_open_mem_host": (c_void_p, [c_void_p, c_void_p, ctypes.c_longlong, c_int]),
     "mprg_ingest_info_host": (None, [c_void_p, c_void_p]),
     "mprg_ingest_fill_host": (None, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "mprg_ingest_text_host": (ctypes.c_longlong, [c_void_p, ctypes.c_longlong, c_void_p]),

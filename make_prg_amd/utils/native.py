@@ -18,6 +18,7 @@ HOST_SIGNATURES = {
     "mprg_fasta_scan_host": (_LL, [_P, _LL, _P, _P]),
     "mprg_fasta_fill_host": (_LL, [_P, _LL, _P, _LL, _P]),
     "mprg_ingest_open_host": (_P, [_P, _LL, ctypes.c_int]),
+    "mprg_ingest_open_mem_host": (_P, [_P, _P, _LL, ctypes.c_int]),
     "mprg_ingest_info_host": (None, [_P, _P]),
     "mprg_ingest_fill_host": (None, [_P, _P, _P, _P, _P, ctypes.c_int]),
     "mprg_ingest_text_host": (_LL, [_P, _LL, _P]),
