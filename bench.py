@@ -360,6 +360,11 @@ def main():
         except Exception:
             avail_kib = 64 << 20
         W = max(1, min(W, max(1, (ncpu - 1) // max(world, 1)), int(avail_kib / (4 << 20) / 4 / max(world, 1))))
+    # one host worker on the GPU: nothing else fills the device while a round's two or three launch lists (independent launches
+    # of different kernels) drain one after the other, so they go to side streams (forest.KM_SIDE_STREAMS; measured, one worker:
+    # +11 % at 3 750 alignments per step, +1 % at 30 000; with four workers sharing the GPU: -4 %, off)
+    if W <= 1:
+        os.environ.setdefault("MPRG_KM_SIDE_STREAMS", "1")
     gen_procs = args.gen_procs or max(1, min(16, ncpu // (max(W, 1) * max(world, 1))))
     parts = lpt_parts(seeds, W) if W > 1 else [seeds]
     cli_dir = None
@@ -604,7 +609,7 @@ def main():
                                    "SURVEY.md §8d generator, seeds 0..batch-1), -N 5 -L 7; one step = every alignment of the job, "
                                    "resident, sharded over the ranks by size (--weak: all of them on every rank)",
                        "alignments_per_step": msas_per_step, "alignments_rank0": len(seeds), "parallelism": f"shard{world}",
-                       "host_worker_processes_per_gpu": W, "cpus_rank0": ncpu, "single_worker": single, "cli": cli,
+                       "host_worker_processes_per_gpu": W, "cpus_rank0": ncpu, "km_side_streams": os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0", "single_worker": single, "cli": cli,
                        "streams_per_worker": args.streams, "event_timing_in_timed_region": bool(args.profile_timed),
                        "step_includes": "recursion forest (kernels + device-side bookkeeping; the host sizes buffers from one header per "
                                         "step) + PRG text laid out and written on the device + its copy to pinned host memory",
