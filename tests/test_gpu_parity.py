@@ -33,6 +33,14 @@ def test_synthetic_config_c_and_deep(hip, golden_synthetic):
     assert pc.check_synthetic(hip, golden_synthetic, configs=("C", "Dsmall")) == 7
 
 
+def test_round_lists_on_side_streams(hip, golden_synthetic, monkeypatch):
+    """forest.KM_SIDE_STREAMS (what bench.py switches on for a rank with one host worker): a round's launch lists forked to side
+    streams and joined; same trees, same PRGs."""
+    import make_prg_amd.forest as forest
+    monkeypatch.setattr(forest, "KM_SIDE_STREAMS", True)
+    assert pc.check_synthetic(hip, golden_synthetic, configs=("B", "C")) >= 40
+
+
 def test_compact_columns(hip):
     """A8 on the device (mprg_compact_columns); the tree dumps of the tests above go through it too (node.alignment)."""
     assert pc.check_compact_columns(hip) == 6
