@@ -251,13 +251,26 @@ def consensus_from_counts(upper: np.ndarray, counts: np.ndarray, first: np.ndarr
     return out
 
 
-def load_alignment_text(text: str, defer_n: bool = False) -> MSA:
+def load_alignment_text(text: str, defer_n: bool = False, alignment_format: str = "fasta") -> MSA:
     """utils/io_utils.py:17-49: parse, upper-case, overwrite every N with its column's majority-consensus base.
     defer_n: leave the N in place and mark the alignment (`pending_n`): the batch engine then gets the column counts
-    from the device (mprg_column_residue_counts) for all such alignments of a batch at once."""
+    from the device (mprg_column_residue_counts) for all such alignments of a batch at once.
+    alignment_format: "fasta", or one of utils/align_formats.FORMATS (restated readers, see there)."""
     from .utils import native
-    parsed = native.parse_fasta(text)          # libmprg's two-pass host parser (plain ASCII text; else the Python one)
-    if parsed is not None:
+    if alignment_format.lower() != "fasta":
+        from .utils.align_formats import read_alignment
+        recs = read_alignment(text, alignment_format)
+        msa = MSA([Record(seq, rid, desc) for rid, desc, seq in recs])
+        data = msa.data.copy()
+        lower = (data >= ord("a")) & (data <= ord("z"))
+        data[lower] -= 32
+        out = MSA(_data=data, _ids=msa.ids, _descs=msa.descriptions)
+        parsed = None
+    else:
+        parsed = native.parse_fasta(text)          # libmprg's two-pass host parser (plain ASCII text; else the Python one)
+    if alignment_format.lower() != "fasta":
+        pass
+    elif parsed is not None:
         data, titles = parsed
         if len(titles) == 0:
             raise ValueError("No records found in handle")
@@ -284,13 +297,11 @@ def load_alignment_text(text: str, defer_n: bool = False) -> MSA:
 
 
 def load_alignment_file(msa_file, alignment_format: str = "fasta", defer_n: bool = False) -> MSA:
-    if alignment_format != "fasta":
-        raise ValueError("only the fasta alignment format is supported by the MI355X path")
     if isinstance(msa_file, StringIO):
-        return load_alignment_text(msa_file.getvalue(), defer_n)
+        return load_alignment_text(msa_file.getvalue(), defer_n, alignment_format)
     path = str(msa_file)
     if path.endswith(".gz"):
         with gzip.open(path, "rt") as fh:
-            return load_alignment_text(fh.read(), defer_n)
+            return load_alignment_text(fh.read(), defer_n, alignment_format)
     with open(path) as fh:
-        return load_alignment_text(fh.read(), defer_n)
+        return load_alignment_text(fh.read(), defer_n, alignment_format)

@@ -38,7 +38,7 @@ def register_parser(subparsers):
     p.add_argument("-o", "--output-prefix", dest="output_prefix", action="store", type=str, required=True,
                    help="Prefix for the output files")
     p.add_argument("-f", "--alignment-format", dest="alignment_format", action="store", default="fasta",
-                   help="Alignment format of MSA. Default: %(default)s")
+                   help="Alignment format of MSA: fasta, clustal, stockholm, phylip, phylip-sequential, phylip-relaxed. Default: %(default)s")
     p.add_argument("-N", "--max-nesting", dest="max_nesting", action="store", type=int, default=NESTING_LVL,
                    help="Maximum number of levels to use for nesting. Default: %(default)d")
     p.add_argument("-L", "--min-match-length", dest="min_match_length", action="store", type=int, default=MIN_MATCH_LEN,
