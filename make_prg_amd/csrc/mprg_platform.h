@@ -71,6 +71,35 @@ MPRG_DEV int block_scan_excl(int v, int *scratch, int *total) {
   return out;
 }
 
+// DPP quad permute of a double: lane L of every quad (lanes 4m .. 4m+3) reads the quad's lane (CTRL >> 2 (L & 3)) & 3; the
+// lanes it reads must be active.  One VALU move per 32-bit half, no LDS crossbar.
+template <int CTRL> MPRG_DEV double quad_perm(double v) {
+  int w[2];
+  __builtin_memcpy(w, &v, 8);
+  w[0] = __builtin_amdgcn_mov_dpp(w[0], CTRL, 0xf, 0xf, true);
+  w[1] = __builtin_amdgcn_mov_dpp(w[1], CTRL, 0xf, 0xf, true);
+  double r;
+  __builtin_memcpy(&r, w, 8);
+  return r;
+}
+// 8 consecutive doubles at p fetched by a GROUP of G lanes (G = 4: a quad, G = 2: a pair — lanes 2m, 2m+1) that all run the
+// same item: lane g of the group loads its 8 / G doubles, the pieces go round by quad_perm, every lane ends with all 8.
+// The address unit of the vector L1 walks one cache line per lane and load instruction whatever the lane takes from it
+// (24 lines per load instruction measured, profiles/r03/kmeans_counters.md): 1 / G of the load instructions per row is 1 / G of
+// its line-cycles.
+template <int G> MPRG_DEV void group_fetch8(const double *p, int g, double *out);
+template <> MPRG_DEV void group_fetch8<4>(const double *p, int g, double *out) {
+  const double l0 = p[2 * g], l1 = p[2 * g + 1];
+  out[0] = quad_perm<0x00>(l0); out[1] = quad_perm<0x00>(l1); out[2] = quad_perm<0x55>(l0); out[3] = quad_perm<0x55>(l1);
+  out[4] = quad_perm<0xaa>(l0); out[5] = quad_perm<0xaa>(l1); out[6] = quad_perm<0xff>(l0); out[7] = quad_perm<0xff>(l1);
+}
+template <> MPRG_DEV void group_fetch8<2>(const double *p, int g, double *out) {
+  const double l0 = p[4 * g], l1 = p[4 * g + 1], l2 = p[4 * g + 2], l3 = p[4 * g + 3];
+  // quad lanes {0, 1} read lane h, lanes {2, 3} read lane 2 + h: [h, h, 2 + h, 2 + h]
+  out[0] = quad_perm<0xa0>(l0); out[1] = quad_perm<0xa0>(l1); out[2] = quad_perm<0xa0>(l2); out[3] = quad_perm<0xa0>(l3);
+  out[4] = quad_perm<0xf5>(l0); out[5] = quad_perm<0xf5>(l1); out[6] = quad_perm<0xf5>(l2); out[7] = quad_perm<0xf5>(l3);
+}
+
 // ---- cell codes and view accessors (layout: include/mprg.h)
 #define C_GAP 4
 #define C_N 11

@@ -261,6 +261,8 @@ MPRG_EMU_SHFL(long long)
 MPRG_EMU_SHFL(unsigned long long)
 MPRG_EMU_SHFL(float)
 MPRG_EMU_SHFL(double)
+// DPP move, quad_perm controls (0x00 .. 0xff): lane L reads lane (ctrl >> 2 (L & 3)) & 3 of its quad
+static inline int __builtin_amdgcn_mov_dpp(int v, int ctrl, int, int, bool) { return __shfl(v, (ctrl >> (2 * ((int)threadIdx.x & 3))) & 3, 4); }
 __attribute__((noinline)) static int __builtin_amdgcn_readfirstlane(int v) { return (int)emu::wave_op(emu::OP_FIRST, (uint64_t)(uint32_t)v, 0, 64, MPRG_EMU_SITE()); }
 static inline int __lane_id() { return (int)(emu::cur & 63); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
