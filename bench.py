@@ -363,7 +363,7 @@ def main():
     # one host worker on the GPU: nothing else fills the device while a round's two or three launch lists (independent launches
     # of different kernels) drain one after the other, so they go to side streams (forest.KM_SIDE_STREAMS; measured, one worker:
     # +11 % at 3 750 alignments per step, +1 % at 30 000; with four workers sharing the GPU: -4 %, off)
-    if W <= 1:
+    if W == 1:          # (not --workers 0: the rocprofv3 runs want one kernel at a time)
         os.environ.setdefault("MPRG_KM_SIDE_STREAMS", "1")
     gen_procs = args.gen_procs or max(1, min(16, ncpu // (max(W, 1) * max(world, 1))))
     parts = lpt_parts(seeds, W) if W > 1 else [seeds]

@@ -302,7 +302,8 @@ class ForestEngine(BatchEngine):
             # the round's fits, already sorted into launch lists by the control step; the lists are independent launches of
             # different kernels: side by side on side streams, so that one list's tail (its last, longest fits) overlaps the others
             todo = [(c, int(hk[86 + c])) for c in range(len(KM_LISTS)) if hk[86 + c]]
-            n_side = len(todo) if (len(todo) > 1 and KM_SIDE_STREAMS and be.n_side_streams >= len(todo)) else 0
+            # (not while per-entry-point events are recorded: they would time launches that overlap)
+            n_side = len(todo) if (len(todo) > 1 and KM_SIDE_STREAMS and be.profile is None and be.n_side_streams >= len(todo)) else 0
             if n_side:
                 be.fork(n_side)
             for q, (c, n_c) in enumerate(todo):
