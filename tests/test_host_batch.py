@@ -1,5 +1,6 @@
 """libmprg_host.so's batch stages on their own (no GPU): the folding CRC-32 against zlib, the pooled one-pass encoders against
 the per-locus encoders, pool reuse."""
+import os
 import random
 import zlib
 
@@ -96,3 +97,37 @@ def test_encode_batch_equals_per_locus(lib):
                 assert int(info[0]) == mapped       # nothing new was mapped for the same work
     finally:
         lib.mprg_encode_pool_free_host(pool)
+
+
+def test_ingest_from_memory_equals_ingest_from_files(lib, tmp_path):
+    """mprg_ingest_open_mem_host (texts in memory, nothing copied) against mprg_ingest_open_host on the same texts as files:
+    same status / rows / columns / title bytes / flags, same matrices and titles."""
+    import ctypes
+    texts = [b">a x\nACGT-N\n>b\nacgtta\n", b">r1\nAC\nGT\n>r2\nACGT\n", b"\x1f\x8bnot really gzip", b">a\nAC\n>a\nAG\n", b"", b">x\nACG\n>y\nAC\n"]
+    paths = []
+    for i, t in enumerate(texts):
+        p = tmp_path / f"f{i}.fa"
+        p.write_bytes(t)
+        paths.append(p)
+    n = len(texts)
+    blob = b"".join(os.fsencode(str(p)) + b"\0" for p in paths)
+    h_file = lib.mprg_ingest_open_host(blob, n, 3)
+    ptrs = (ctypes.c_char_p * n)(*texts)
+    lens = np.array([len(t) for t in texts], np.int64)
+    h_mem = lib.mprg_ingest_open_mem_host(ptrs, lens.ctypes.data, n, 3)
+    info_f, info_m = np.zeros((n, 5), np.int64), np.zeros((n, 5), np.int64)
+    lib.mprg_ingest_info_host(h_file, info_f.ctypes.data)
+    lib.mprg_ingest_info_host(h_mem, info_m.ctypes.data)
+    assert np.array_equal(info_f, info_m)
+    assert info_f[:, 0].tolist() == [0, 0, -3, 0, -7, -5] and info_f[3, 4] & 1 and info_f[0, 4] & 2
+    ok = info_f[:, 0] == 0
+    sizes = np.where(ok, info_f[:, 1] * info_f[:, 2], 0)
+    raw_off = np.where(ok, np.cumsum(sizes) - sizes, -1)
+    t_off = np.cumsum(np.where(ok, info_f[:, 3], 0)) - np.where(ok, info_f[:, 3], 0)
+    outs = []
+    for h in (h_file, h_mem):
+        arena, titles = np.zeros(int(sizes.sum()) + 1, np.uint8), np.zeros(int(info_f[ok, 3].sum()) + 1, np.uint8)
+        lib.mprg_ingest_fill_host(h, arena.ctypes.data, raw_off.ctypes.data, titles.ctypes.data, t_off.ctypes.data, 2)
+        outs.append((arena.tobytes(), titles.tobytes()))
+        lib.mprg_ingest_close_host(h)
+    assert outs[0] == outs[1] and outs[0][0].startswith(b"ACGT-NACGTTA") and outs[0][1].startswith(b"a x\nb\n")
