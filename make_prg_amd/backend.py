@@ -109,6 +109,16 @@ class MprgError(RuntimeError):
     pass
 
 
+def _library_is_mapped(path: str) -> bool:
+    """Is this shared object already loaded in this process?"""
+    try:
+        real = os.path.realpath(path)
+        with open("/proc/self/maps") as fh:
+            return any(line.rstrip().endswith(real) for line in fh)
+    except OSError:
+        return False
+
+
 def bind(lib):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
@@ -174,6 +184,12 @@ class HipBackend(_Base):
     name = "hip"
 
     def __init__(self, device: Optional[int] = None, lib_path: str = HIP_LIB_PATH, own_stream: bool = False):
+        import sys
+        if "torch" not in sys.modules and _library_is_mapped(lib_path):
+            # torch loads ITS copy of the HIP runtime by path; a library bound to the system's copy would then hand torch's
+            # pointers to a runtime that never saw them (hipMemsetAsync: invalid value)
+            raise MprgError(f"{os.path.basename(lib_path)} was loaded in this process before torch: use the runtime backend "
+                            "(MPRG_BACKEND=runtime, make_backend('runtime')) or import torch first")
         import torch
         if not os.path.exists(lib_path):
             raise MprgError(f"{lib_path} not found: build it with `python __graft_entry__.py build` (hipcc, gfx950)")
