@@ -437,7 +437,8 @@ uint32_t mprg_crc32_host(uint32_t crc, const void *data, long long len);
  * runtime the library is linked against.  Pointers: NULL on failure; ints: 0 or a negative code; mprg_last_error() says what.
  * mprg_rt_host_malloc: page-locked host memory that kernels may also write (result headers).  mprg_rt_memcpy_async kinds below;
  * pageable host memory makes a copy synchronous.  mprg_rt_event_query: 0 done, 1 not yet.  Streams are non-blocking streams;
- * every kernel entry point above takes one as its `stream` argument. */
+ * every kernel entry point above takes one as its `stream` argument.  mprg_rt_init(device) makes `device` current for the CALLING
+ * THREAD (HIP's current device is per thread; a new thread starts on device 0): call it in every thread that allocates or launches. */
 enum { MPRG_RT_H2D = 1, MPRG_RT_D2H = 2, MPRG_RT_D2D = 3 };
 int mprg_rt_device_count(void);
 int mprg_rt_init(int device);

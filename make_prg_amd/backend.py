@@ -356,6 +356,9 @@ class _RtHostBuffer:
         return self.nbytes
 
 
+_rt_thread = __import__("threading").local()          # .device: the HIP device this THREAD was last switched to
+
+
 class _RtEvent:
     def __init__(self, lib, timing: bool):
         self.lib = lib
@@ -396,8 +399,9 @@ class HipRuntimeBackend(_Base):
             raise MprgError("no ROCm device visible: make_prg_amd has no CPU fallback")
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0")) % n
-        self._check(self.lib.mprg_rt_init(device), "device")
         self.device = device
+        _rt_thread.device = None
+        self._on_device()
         self.stream = self._ptr(self.lib.mprg_rt_stream_create(), "stream")
         self._free = {}                       # capacity -> addresses ready for reuse
         self._host = []                       # page-locked blocks, freed at close()
@@ -407,6 +411,18 @@ class HipRuntimeBackend(_Base):
     def _check(self, rc, what):
         if rc != 0:
             raise MprgError(f"{what} failed ({rc}): {self.lib.mprg_last_error().decode()}")
+
+    def _on_device(self):
+        """HIP's current device is a property of the calling THREAD (a new thread starts on device 0): every allocation, stream,
+        event and launch of this backend first makes sure the thread is on the backend's device — bench.py and the tests drive
+        engines from pool threads, and ranks of a multi-GPU job do not sit on device 0."""
+        if getattr(_rt_thread, "device", None) != self.device:
+            self._check(self.lib.mprg_rt_init(self.device), "device")
+            _rt_thread.device = self.device
+
+    def call(self, name, *args, work: float = 0.0, side: Optional[int] = None):
+        self._on_device()
+        return super().call(name, *args, work=work, side=side)
 
     def _ptr(self, p, what):
         if not p:
@@ -430,6 +446,7 @@ class HipRuntimeBackend(_Base):
         free = self._free.get(cap)
         if free:
             return _RtBuffer(self, free.pop(), cap, nbytes)
+        self._on_device()
         addr = self.lib.mprg_rt_malloc(cap)
         if not addr:          # give what the free lists hold back to the runtime and try once more
             self.trim()
@@ -444,16 +461,12 @@ class HipRuntimeBackend(_Base):
                 self.lib.mprg_rt_free(a)
         self._free = {}
 
-    def zeros(self, nbytes: int):
-        buf = self.empty(nbytes)
-        self._check(self.lib.mprg_rt_memset_async(buf.mprg_addr, 0, buf.nbytes, self.stream), "memset")
-        return buf
-
     def upload(self, arr: np.ndarray):
         arr = np.ascontiguousarray(arr)
         if arr.nbytes == 0:
             return self.empty(16)
         buf = self.empty(arr.nbytes)
+        self._on_device()
         self._check(self.lib.mprg_rt_memcpy_async(buf.mprg_addr, arr.ctypes.data, arr.nbytes, 1, self.stream), "upload")
         self._check(self.lib.mprg_rt_stream_sync(self.stream), "upload")          # pageable source: it may go away after this call
         return buf
@@ -461,11 +474,13 @@ class HipRuntimeBackend(_Base):
     def download(self, buf, dtype, count: int) -> np.ndarray:
         out = np.empty(int(count), dtype)
         if out.nbytes:
+            self._on_device()
             self._check(self.lib.mprg_rt_memcpy_async(out.ctypes.data, self.ptr(buf), out.nbytes, 2, self.stream), "download")
             self._check(self.lib.mprg_rt_stream_sync(self.stream), "download")
         return out
 
     def _host_block(self, nbytes: int) -> _RtHostBuffer:
+        self._on_device()
         hb = _RtHostBuffer(self._ptr(self.lib.mprg_rt_host_malloc(int(nbytes)), f"page-locked allocation of {nbytes} bytes"), int(nbytes))
         self._host.append(hb)
         return hb
@@ -482,6 +497,7 @@ class HipRuntimeBackend(_Base):
         if nbytes == 0:
             return self.empty(16)
         buf = self.empty(nbytes)
+        self._on_device()
         self._check(self.lib.mprg_rt_memcpy_async(buf.mprg_addr, pinned_buf.mprg_addr, int(nbytes), 1, self.stream), "upload")
         return buf
 
@@ -498,6 +514,7 @@ class HipRuntimeBackend(_Base):
     def download_async(self, buf, nbytes: int, group: int = 0):
         """As HipBackend.download_async: copy stream, `async_depth` page-locked buffers per group used in turn."""
         nbytes = int(nbytes)
+        self._on_device()
         if not hasattr(self, "_pinned"):
             self._pinned, self._parity = {}, {}
             self._copy_stream = self._ptr(self.lib.mprg_rt_stream_create(), "stream")
@@ -527,13 +544,16 @@ class HipRuntimeBackend(_Base):
     def grown(self, buf, used_bytes: int, new_bytes: int):
         new = self.empty(int(new_bytes))
         if used_bytes:
+            self._on_device()
             self._check(self.lib.mprg_rt_memcpy_async(new.mprg_addr, self.ptr(buf), int(used_bytes), 3, self.stream), "copy")
         return new
 
     def synchronize(self):
+        self._on_device()
         self._check(self.lib.mprg_rt_stream_sync(self.stream), "synchronize")
 
     def _event_pair(self):
+        self._on_device()
         return (_RtEvent(self.lib, True), _RtEvent(self.lib, True))
 
     def _record(self, event, side):
@@ -542,6 +562,7 @@ class HipRuntimeBackend(_Base):
     n_side_streams = 3
 
     def _sides(self, n):
+        self._on_device()
         if not hasattr(self, "_side"):
             self._side = []
         while len(self._side) < n:
@@ -552,6 +573,7 @@ class HipRuntimeBackend(_Base):
         return self._sides(i + 1)[i]
 
     def fork(self, n: int):
+        self._on_device()
         ev = _RtEvent(self.lib, False)
         ev.record(self.stream)
         for s_ in self._sides(n):
@@ -562,6 +584,12 @@ class HipRuntimeBackend(_Base):
             ev = _RtEvent(self.lib, False)
             ev.record(s_)
             self.lib.mprg_rt_stream_wait_event(self.stream, ev.h)
+
+    def zeros(self, nbytes: int):
+        buf = self.empty(nbytes)
+        self._on_device()
+        self._check(self.lib.mprg_rt_memset_async(buf.mprg_addr, 0, buf.nbytes, self.stream), "memset")
+        return buf
 
 
 def make_backend(kind: Optional[str] = None, device: Optional[int] = None, own_stream: bool = True):

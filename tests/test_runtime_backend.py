@@ -61,3 +61,30 @@ def test_copies_and_events(rt):
 def test_forest_through_the_runtime_backend(rt, golden_integration, golden_synthetic):
     assert pc.check_integration(rt, golden_integration) >= 30
     assert pc.check_synthetic(rt, golden_synthetic, configs=("B",), limit=6) == 6
+
+
+def test_every_thread_is_switched_to_the_backends_device(rt):
+    """HIP's current device belongs to the calling thread: a pool thread that drives an engine (bench.py, ranks beyond device 0)
+    must be put on the backend's device before its first allocation / launch — once per thread."""
+    import threading
+    calls = []
+    real = rt.lib.mprg_rt_init
+
+    def counting(dev):
+        calls.append((threading.get_ident(), dev))
+        return real(dev)
+
+    rt.lib.mprg_rt_init = counting
+    try:
+        def work():
+            a = rt.empty(3_000_001)          # a size class nothing else used: a real allocation
+            z = rt.zeros(100)
+            rt.synchronize()
+            assert len(a) == 3_000_001 and not rt.download(z, np.uint8, 100).any()
+        t = threading.Thread(target=work)
+        t.start(); t.join()
+        assert len(calls) == 1 and calls[0][0] != threading.get_ident() and calls[0][1] == rt.device
+        rt.empty(64)                         # this thread was switched when the backend was made
+        assert len(calls) == 1
+    finally:
+        rt.lib.mprg_rt_init = real
