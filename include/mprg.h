@@ -204,6 +204,13 @@ int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, const int32_t *fi
  * (int32 [n]) receives the permutation, ok[0] = 1 (0: more than 5^10 elements).  Exposed for its own parity test; the KMeans
  * kernels run the same code inside a fit. */
 int mprg_argpartition(const double *values, int32_t *perm, int n, int kth, int32_t *ok, void *stream);
+/* the SPLIT form of mprg_kmeans_fit for launches that would not fill the device: a 64-thread workgroup per RESTART (n_fits *
+ * n_init of them, restart r on slot `first slot + r` of the problem's workspace), then the selection over the same fit list in a
+ * second launch.  Same arithmetic and results as mprg_kmeans_fit; more total work (what a fit's restarts share is redone per
+ * restart), a shorter launch when the device would otherwise idle. */
+int mprg_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
+                          const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
+                          int32_t *km_status, void *stream);
 int mprg_kmeans_wave_class(int64_t D, int64_t V, int k);
 /* A11, the workgroup form for SMALL fits: 128-thread workgroups with a trimmed static LDS (8 KB pool; small_class 0 also a
  * 6 x 6 centre-centre table, i.e. k <= 6), so that 6-8 fits are resident per CU instead of 4.  mprg_kmeans_small_class(D, V, k,

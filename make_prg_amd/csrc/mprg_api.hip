@@ -206,6 +206,18 @@ int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, const int32_t *fi
   return check_launch("k_kmeans_fit");
 }
 
+int mprg_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
+                          const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
+                          int32_t *km_status, void *stream) {
+  if (n_fits <= 0) return 0;
+  if (n_init < 1 || n_init > KM_RMAX) return fail("n_init must be 1..16");
+  hipLaunchKernelGGL(k_kmeans_restart_one, dim3((unsigned)((long long)n_fits * n_init)), dim3(64), 0, (hipStream_t)stream, prob, kinfo, fit_list,
+                     n_init, uniforms_dev, xcounts, ws, km_status);
+  if (check_launch("k_kmeans_restart_one") != 0) return -2;
+  LAUNCH(k_kmeans_select_list, n_fits, 256, stream, prob, kinfo, fit_list, n_init, xcounts, ws, labels, km_info);
+  return check_launch("k_kmeans_select_list");
+}
+
 int mprg_kmeans_wave_class(int64_t D, int64_t V, int k) { return (k < 2 || k > KM_KMAX) ? -1 : km_wave_class_host(D, V, k); }
 
 int mprg_kmeans_fit_wave(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int lds_class, int n_init,

@@ -49,6 +49,9 @@ KM_MODE = int(os.environ.get("MPRG_KM_MODE", "2"))
 # a round's launch lists side by side on side streams: measured flat on MI355X (352 vs 354 ms per forest of 30 000 alignments,
 # profiles/r03/kmeans_forms.md), off by default
 KM_SIDE_STREAMS = os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0"
+# a launch list of at most this many fits goes through the SPLIT form (a workgroup per restart + a selection launch,
+# mprg_kmeans_fit_split): such a launch lasts one fit latency whatever it holds (profiles/r03/kmeans_split.md); 0 = never
+KM_SPLIT_BELOW = int(os.environ.get("MPRG_KM_SPLIT_BELOW", "0"))
 F_FIELDS = 96
 PREPARE_CLASSES = 4                      # LDS classes of mprg_kmeans_prepare (+ the global-memory form)
 
@@ -308,15 +311,20 @@ class ForestEngine(BatchEngine):
                 be.fork(n_side)
             for q, (c, n_c) in enumerate(todo):
                 entry, cls = KM_LISTS[c]
+                list_entry = entry                    # (the list's algorithmic bytes are credited under this name, split or not)
                 lst = be.ptr(d_fl) + 4 * c * P
                 stream = be.side_ptr(q) if n_side else be.stream
                 outs = out_args[:-1] + (stream,)
-                if cls is None:
+                if n_c <= KM_SPLIT_BELOW:
+                    entry = "mprg_kmeans_fit_split"
+                    be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, *outs, side=q if n_side else None)
+                elif cls is None:
                     be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, 0, 0, 0, 0, *outs, side=q if n_side else None)
                 else:
                     be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, cls, N_INIT, *fit_args, *outs, side=q if n_side else None)
-                km_events.append(self._last_event(entry))
-                self.counters["launches"] += 1
+                ev = self._last_event(entry)
+                km_events.append(ev and ev + (list_entry,))
+                self.counters["launches"] += 1 + (entry == "mprg_kmeans_fit_split")
             if n_side:
                 be.join(n_side)
             self._cluster_further(d_sub, d_ptab, P, k, dd, d_labels, d_assign, d_wc, n_wc, d_wr, n_wr, d_scratch, d_further, d_info, d_kinfo)
@@ -335,7 +343,7 @@ class ForestEngine(BatchEngine):
         self.counters["kmeans_bytes"] += km_bytes
         # algorithmic bytes are known only after the fits: 8 D V (iterations + n_init)
         for entry, nbytes in kb.items():
-            self._credit([e for e in km_events if e and e[0] == entry], nbytes)
+            self._credit([e[:2] for e in km_events if e and e[2] == entry], nbytes)
         self._credit(cf_events, cf_cells)
         if n_splits == 0:
             return 0

@@ -49,6 +49,10 @@ def run_kmeans_fits(be, fits, n_init=10, path="global", n_slots=3):
             d_slots = be.empty(8 * stride * n_slots)
             be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), None, P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws),
                     be.ptr(d_slots), stride, n_slots, be.ptr(be.empty(16)), be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
+        elif path == "split":          # a workgroup per restart, then the selection over the list (every other fit listed: the list is used)
+            d_l = be.upload(np.arange(P, dtype=np.int32))
+            be.call("mprg_kmeans_fit_split", be.ptr(d_p), be.ptr(d_ki), be.ptr(d_l), P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws),
+                    be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
         elif path == "one-launch":
             be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), None, P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, 0,
                     be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)

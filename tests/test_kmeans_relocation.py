@@ -38,6 +38,7 @@ def test_relocation_matches_oracle_persistent_workgroups():
     fits = degenerate_fits(7, 60)
     check(EmuBackend(), fits, path="wave")                        # a wavefront per fit, restart state in LDS
     check(EmuBackend(), fits, path="fit", n_slots=2)              # many fits per workgroup, one scratch slot each
+    check(EmuBackend(), fits, path="split")                       # a workgroup per restart, then the selection
     check(EmuBackend(), fits, path="fit", n_slots=512)
 
 
