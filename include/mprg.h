@@ -131,7 +131,7 @@ int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t 
  * table: uint64 keys[cap] then uint32 minocc[cap], uint32 id[cap] per problem (cap = power of two >= 2*T).
  * Keys: the k-mer packed at 4 bits per character for kmer_size <= 16; beyond, a seeded 64-bit hash whose every use is verified
  * character by character (a collision rebuilds the dictionary with the next seed), so ids are exact for any k-mer size.
- * out_V[n_probs] = number of distinct k-mers (bits 0-23) | the hash seed that held << 24 (0x7f: none of 64 did).  The seed must
+ * out_V[n_probs] = number of distinct k-mers (bits 0-23, saturating at 0xffffff) | the hash seed that held << 24 (0x7f: none of 64 did).  The seed must
  * be passed on to mprg_kmer_counts in bits 40+ of prob[MPRG_P_TABLE_CAP]. */
 enum {
   MPRG_P_VIEW = 0, MPRG_P_D = 1, MPRG_P_SEQROW_OFF = 2, MPRG_P_T = 3, MPRG_P_TABLE_OFF = 4, MPRG_P_TABLE_CAP = 5,

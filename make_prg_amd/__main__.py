@@ -50,8 +50,10 @@ def main(argv=None):
 
 if __name__ == "__main__":
     main()
-    if os.environ.get("MPRG_FAST_EXIT", "1") != "0":
-        # every output file is closed by now: skip the interpreter's and the runtimes' tear-down (un-pinning GBs of buffers)
+    if os.environ.get("MPRG_FAST_EXIT", "1") != "0" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # every output file is closed by now: skip the interpreter's and the runtimes' tear-down (un-pinning GBs of buffers).
+        # Only the single-process run: a rank of a torchrun job leaves through the normal shutdown, after its sub-command has
+        # synchronised the device, met the other ranks at a barrier and destroyed the process group.
         logging.shutdown()
         sys.stdout.flush()
         sys.stderr.flush()

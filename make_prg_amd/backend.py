@@ -486,11 +486,59 @@ class HipRuntimeBackend(_Base):
         self._host.append(hb)
         return hb
 
+    def _host_release(self, hb: Optional[_RtHostBuffer]):
+        """Un-pins a block that was REPLACED by a bigger one (pinned() / download_async regrowth).  Everything the streams hold
+        is waited for first: a copy into or out of the old block may still be queued.  Rare (buffers grow by 1/8 headroom)."""
+        if hb is None or hb not in self._host:
+            return
+        self.synchronize()
+        if getattr(self, "_copy_stream", None):
+            self._check(self.lib.mprg_rt_stream_sync(self._copy_stream), "synchronize")
+        self._host.remove(hb)
+        hb.array = None
+        self.lib.mprg_rt_host_free(hb.mprg_addr)
+
+    def close(self):
+        """Gives everything back to the runtime: waits for the streams, then hipFree of the free lists, hipHostFree of every
+        page-locked block, the streams destroyed.  Buffers still referenced by the caller must not be used afterwards (their
+        blocks are NOT freed: they were never returned to the free lists).  Idempotent; also run when the backend is collected."""
+        if self._free is None:
+            return
+        try:
+            self._on_device()
+            self.lib.mprg_rt_stream_sync(self.stream)
+            for st in [getattr(self, "_copy_stream", None)] + list(getattr(self, "_side", [])):
+                if st:
+                    self.lib.mprg_rt_stream_sync(st)
+            self._pending = []
+            free, self._free = self._free, None          # (None: a buffer dropped from now on is not put on a list)
+            for addrs in free.values():
+                for a in addrs:
+                    self.lib.mprg_rt_free(a)
+            for hb in self._host:
+                hb.array = None
+                self.lib.mprg_rt_host_free(hb.mprg_addr)
+            self._host = []
+            self._pinned_up, self._pinned, self._hdr_block = {}, {}, None
+            for st in [getattr(self, "_copy_stream", None)] + list(getattr(self, "_side", [])) + [self.stream]:
+                if st:
+                    self.lib.mprg_rt_stream_destroy(st)
+            self._copy_stream, self._side, self.stream = None, [], None
+        except Exception:
+            pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def pinned(self, nbytes: int, key):
         if not hasattr(self, "_pinned_up"):
             self._pinned_up = {}
         hb = self._pinned_up.get(key)
         if hb is None or hb.nbytes < nbytes:
+            self._host_release(hb)
             hb = self._pinned_up[key] = self._host_block(max(int(nbytes) + (int(nbytes) >> 3), 1 << 20))
         return hb, hb.array
 
@@ -503,9 +551,13 @@ class HipRuntimeBackend(_Base):
         return buf
 
     def host_visible(self, nbytes: int):
-        hb = self._host_block(max(int(nbytes), 16))
-        hb.array[:] = 0
-        return hb, hb.array
+        """One block per backend, reused by every engine (an engine reads its header right after the wait for its own step;
+        engines of one backend run one after the other on its stream)."""
+        hb = getattr(self, "_hdr_block", None)
+        if hb is None or hb.nbytes < nbytes:
+            hb = self._hdr_block = self._host_block(max(int(nbytes), 16))
+            hb.array[:] = 0
+        return hb, hb.array[:max(int(nbytes), 16)]
 
     def _reap(self):
         """Drops the buffers whose copies on the copy stream are done."""
@@ -517,17 +569,28 @@ class HipRuntimeBackend(_Base):
         nbytes = int(nbytes)
         self._on_device()
         if not hasattr(self, "_pinned"):
-            self._pinned, self._parity = {}, {}
+            self._pinned, self._parity, self._retired, self._turns = {}, {}, [], {}
             self._copy_stream = self._ptr(self.lib.mprg_rt_stream_create(), "stream")
         depth = getattr(self, "async_depth", 2)
         par = self._parity.get(group, 0) % depth
         self._parity[group] = par + 1
+        turn = self._turns[group] = self._turns.get(group, 0) + 1          # calls of this group so far
         host = self._pinned.get((group, par))
         if host is None or host.nbytes < nbytes:
             for q in range(depth):
                 if self._pinned.get((group, q)) is None or self._pinned[(group, q)].nbytes < nbytes:
+                    # the replaced block may still be read by whoever received it (a result stays valid until the depth-th
+                    # following call of its group): it is un-pinned once the ring has gone round
+                    if self._pinned.get((group, q)) is not None:
+                        self._retired.append((group, turn + depth, self._pinned[(group, q)]))
                     self._pinned[(group, q)] = self._host_block(max(nbytes + (nbytes >> 3), 1 << 20))
             host = self._pinned[(group, par)]
+        if self._retired:
+            due = [r for r in self._retired if r[0] == group and r[1] <= turn]
+            if due:
+                self._retired = [r for r in self._retired if r not in due]
+                for _, _, hb in due:
+                    self._host_release(hb)
         self._reap()
         ready = _RtEvent(self.lib, False)
         ready.record(self.stream)

@@ -563,7 +563,10 @@ class BatchEngine:
             p["V"] = int(V[i])
             ptab[i, 7], ptab[i, 8], ptab[i, 9], ptab[i, 10] = V[i], xo, wo, lo
             xo += p["D"] * int(V[i])
-            wo += int(be.lib.mprg_kmeans_workspace_doubles(p["D"], int(V[i]), MAX_CLUSTERS, N_INIT))
+            need = int(be.lib.mprg_kmeans_workspace_doubles(p["D"], int(V[i]), MAX_CLUSTERS, N_INIT))
+            if need < 0:
+                raise MprgError("a k-mer count matrix has more than 4 194 304 features: beyond the KMeans kernels' pairwise-sum stack")
+            wo += need
             lo += p["D"]
         d_ptab = be.upload(ptab)
         d_x, d_ws = be.zeros(8 * xo), be.empty(8 * wo)

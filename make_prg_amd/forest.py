@@ -433,12 +433,15 @@ def _special_leaf_alleles(self: "ForestEngine", rows: np.ndarray) -> Dict[int, L
     return out
 
 
-def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool = False, lazy: bool = False, export: bool = False):
+def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool = False, lazy: bool = False, export: bool = False,
+                  ring: int = 0):
     """PRG string of every alignment of the batch (None for loci dropped by the curation policy).  lazy: returns a function
     that waits for the text's copy to the host and returns the list — the copy then overlaps whatever the caller enqueues next
     (as_bytes views stay valid until the second following assemble_prgs of this engine's backend).
     want_index: self.prg_index_entries(i) afterwards.  export: self.exported = the trees as per-locus slices of three arrays
     (records, rows, PRG index: mprg_forest_export_* in include/mprg.h) for the update data structure.
+    ring: which set of pinned buffers the copies cycle through (backend.download_async groups 4 * ring ..): a caller that builds
+    a side batch on a backend whose main ring is in use by a pipeline (pipeline.py: the object path of a chunk) takes its own.
     Device (mprg_forest_assemble_*): preorder ranks and site numbers, text lengths bottom-up, text offsets top-down over the
     node table; every leaf's alleles (mprg_emit_alleles) and every marker.  Host: the rare leaves with ambiguity codes.
     reference: PrgBuilder.build_prg prg_builder.py:100-105; traversals recursion_tree.py:194-201, :222-239, :266-300."""
@@ -524,20 +527,20 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool =
     node_bounds = np.concatenate([mb[:, 2], [n]])
     waits = []
     if want_index or export:
-        ix_host, w_ = be.download_async(d_index, 12 * n_jobs, group=1)
+        ix_host, w_ = be.download_async(d_index, 12 * n_jobs, group=4 * ring + 1)
         waits.append(w_)
         job_bounds = bounds(np.where(self.root_of >= 0, mb[:, 1], -1), n_jobs)
         self._index = (ix_host.view(np.int32).reshape(-1, 3), job_bounds)
     if export:
-        rec_host, w1 = be.download_async(d_rec, 32 * n, group=2)
-        rows_host, w2 = be.download_async(d_rows, 4 * n_ex_rows, group=3)
+        rec_host, w1 = be.download_async(d_rec, 32 * n, group=4 * ring + 2)
+        rows_host, w2 = be.download_async(d_rows, 4 * n_ex_rows, group=4 * ring + 3)
         waits += [w1, w2]
         self.exported = dict(records=rec_host.view(np.int32).reshape(-1, 8), rows=rows_host.view(np.int32), node_bounds=node_bounds,
                              row_bounds=bounds(np.where(self.root_of >= 0, mb[:, 3], -1), n_ex_rows),
                              index=self._index[0], index_bounds=self._index[1])
     if host_leaf:
         _ = self.asm, self.tab
-    buf, wait = be.download_async(d_out, total_chars)
+    buf, wait = be.download_async(d_out, total_chars, group=4 * ring)
     waits.append(wait)
     # the text of the host-expanded leaves: placed now (this engine's tables may belong to the next batch by the time the
     # caller collects the text), written into the buffer once the copy has landed

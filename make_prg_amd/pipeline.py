@@ -231,6 +231,8 @@ def run_pipeline(files: List[Path], options, backend) -> int:
     if errors:
         raise errors[0]
     out.close()
+    if callable(backend) and hasattr(be, "close") and os.environ.get("MPRG_FAST_EXIT", "1") == "0":
+        be.close()          # a backend made here is released here (the command line leaves through os._exit instead: un-pinning GBs is slow)
     _trace(f"outputs closed {since_process_start():.2f} s after the process started") if TRACE else None
     return out.n
 
@@ -289,7 +291,9 @@ def _build_chunk(lib, be, options, threads, ci, chunk, h, info):
                 raise m
             msas.append(m)
             loci.append(locus)
-        drv._build_batch(msas, loci, options, be, res["slow_records"])
+        # (its copies cycle through pinned buffers of their OWN: the main ring holds the text / tree export of this chunk and of the
+        #  two before it, which the output stage and the writers may still be reading)
+        drv._build_batch(msas, loci, options, be, res["slow_records"], ring=1)
     if h is not None:
         lib.mprg_ingest_close_host(h)
     return (res,)
@@ -350,16 +354,16 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
         t_addr[i], t_len[i] = _addr(text), len(text)
         for kind in extra:
             if kind in rec:
-                extra[kind].append((names[i] if kind == "pickle" else f"{names[i]}.{kind}", rec[kind]))
+                extra[kind].append((i, names[i] if kind == "pickle" else f"{names[i]}.{kind}", rec[kind]))
     ok = np.zeros(0, bool)
     if n_fast:
         ok = length >= 0
         for j in np.nonzero(ok & (bin_words < 0) & bool(ot.binary))[0].tolist():      # the reference-shaped encoders own these strings
             from .utils.prg_encoder import PrgEncoder
-            extra["bin"].append((names[int(fi[j])] + ".bin", np.asarray(PrgEncoder().encode(bytes(prgs[j]).decode()), "<u4").tobytes()))
+            extra["bin"].append((int(fi[j]), names[int(fi[j])] + ".bin", np.asarray(PrgEncoder().encode(bytes(prgs[j]).decode()), "<u4").tobytes()))
         for j in np.nonzero(ok & (gfa_bytes < 0) & bool(ot.gfa))[0].tolist():
             from .utils.gfa import GFA_Output
-            extra["gfa"].append((names[int(fi[j])] + ".gfa", GFA_Output.gfa_bytes(bytes(prgs[j]).decode())))
+            extra["gfa"].append((int(fi[j]), names[int(fi[j])] + ".gfa", GFA_Output.gfa_bytes(bytes(prgs[j]).decode())))
     built = np.nonzero(t_len >= 0)[0]
     out.n += len(built)
     jobs = []
@@ -371,14 +375,21 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
             _trace(f"chunk {res['ci']}: wrote {name} in {1e3 * (time.perf_counter() - t0):.0f} ms")
         return run
 
-    def zip_job(kind, member_names, addr, ln, crcs):
-        for nm, data in extra[kind]:          # the rare bytes members ride along: one more row each
+    def zip_job(kind, member_names, addr, ln, crcs, place):
+        """place: the chunk position of every member's locus — the archive lists a chunk's members in the run's locus order."""
+        place = list(place)
+        for pos, nm, data in extra[kind]:     # the rare bytes members ride along: one more row each, at their locus's place
             keep.append(data)
             row_a, row_l = np.zeros((1, addr.shape[1]), np.int64), np.zeros((1, addr.shape[1]), np.int64)
             row_a[0, 0], row_l[0, 0] = _addr(data), len(data)
             addr, ln = np.concatenate([addr, row_a]), np.concatenate([ln, row_l])
             member_names = member_names + [nm]
             crcs = np.concatenate([crcs, [zlib.crc32(data)]])
+            place.append(pos)
+        if extra[kind]:
+            order = np.argsort(np.asarray(place, np.int64), kind="stable")
+            addr, ln, crcs = addr[order], ln[order], np.asarray(crcs)[order]
+            member_names = [member_names[q] for q in order.tolist()]
         if len(member_names):
             jobs.append(timed(kind, out.zip(kind).plan_table(member_names, addr, ln, crcs, lib, WRITE_THREADS, keep)))
 
@@ -401,12 +412,14 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
         sel = okj[bin_words[okj] >= 0] if n_fast else okj
         zip_job("bin", [names[i] + ".bin" for i in fi[sel].tolist()] if n_fast else [],
                 bin_addr[sel].reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64),
-                (4 * bin_words[sel]).reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64), crc[sel, 1] if n_fast else np.zeros(0, np.uint32))
+                (4 * bin_words[sel]).reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64), crc[sel, 1] if n_fast else np.zeros(0, np.uint32),
+                fi[sel].tolist() if n_fast else [])
     if ot.gfa:
         sel = okj[gfa_bytes[okj] >= 0] if n_fast else okj
         zip_job("gfa", [names[i] + ".gfa" for i in fi[sel].tolist()] if n_fast else [],
                 gfa_addr[sel].reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64),
-                gfa_bytes[sel].reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64), crc[sel, 2] if n_fast else np.zeros(0, np.uint32))
+                gfa_bytes[sel].reshape(-1, 1) if n_fast else np.zeros((0, 1), np.int64), crc[sel, 2] if n_fast else np.zeros(0, np.uint32),
+                fi[sel].tolist() if n_fast else [])
     if ot.prg:          # update_DS members: header + slices of the arena, the titles and the device's tree export
         K = 7
         n_m = len(okj)
@@ -441,7 +454,7 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
             first = np.arange(n_m + 1, dtype=np.int64) * K
             a_flat, l_flat = np.ascontiguousarray(addr.reshape(-1)), np.ascontiguousarray(ln.reshape(-1))
             lib.mprg_crc32_members_host(a_flat.ctypes.data, l_flat.ctypes.data, first.ctypes.data, n_m, threads, crcs.ctypes.data)
-        zip_job("pickle", ok_names, addr, ln, crcs)
+        zip_job("pickle", ok_names, addr, ln, crcs, fi[okj].tolist() if n_fast else [])
     _trace(f"chunk {res['ci']}: wait for copies {1e3 * (tw1 - tw0):.0f} ms, encode {1e3 * (tw2 - tw1):.0f} ms, "
            f"tables + places {1e3 * (time.perf_counter() - tw2):.0f} ms")
     return jobs

@@ -151,7 +151,8 @@ def locus_record(locus: str, prg: str, builder, output_type) -> dict:
     return rec
 
 
-def _build_batch(msas, loci, options, backend, out: Dict[str, dict]):
+def _build_batch(msas, loci, options, backend, out: Dict[str, dict], ring: int = 0):
+    """ring: the set of pinned download buffers of the backend this batch's copies use (forest.assemble_prgs)."""
     from ..device import get_backend
     from ..prg_builder import PrgBuilder
     from ..recursion_tree import materialise
@@ -174,7 +175,7 @@ def _build_batch(msas, loci, options, backend, out: Dict[str, dict]):
         eng = ForestEngine(be, options.max_nesting, options.min_match_length)
         eng.load([msas[i] for i in uniq])
         eng.run_forest()
-        prgs = eng.assemble_prgs(want_index=ot.prg)
+        prgs = eng.assemble_prgs(want_index=ot.prg, ring=ring)
         for j, i in enumerate(uniq):
             if prgs[j] is None:
                 err = eng.errors[j]

@@ -171,3 +171,66 @@ def test_streamed_pipeline_equals_the_object_path(tmp_path, golden_integration, 
         assert x == y, l
         assert x.build_prg() == y.build_prg()
         assert sorted((k, v.node_id) for k, v in x.prg_index.items()) == sorted((k, v.node_id) for k, v in y.prg_index.items())
+
+
+class _RingEmuBackend(EmuBackend):
+    """EmuBackend whose download_async behaves like the product backends': `async_depth` persistent buffers per group, used in
+    turn and OVERWRITTEN on reuse (the plain emulation hands out a fresh copy per call, which hides ring misuse)."""
+
+    def __init__(self):
+        super().__init__()
+        self.ring, self.turn, self.log = {}, {}, []
+
+    def download_async(self, buf, nbytes, group=0):
+        import numpy as np
+        depth = getattr(self, "async_depth", 2)
+        par = self.turn.get(group, 0) % depth
+        self.turn[group] = par + 1
+        self.log.append(group)
+        host = self.ring.get((group, par))
+        if host is None or host.size < nbytes:
+            host = self.ring[(group, par)] = np.zeros(max(int(nbytes), 16), np.uint8)
+        host[:nbytes] = buf[:int(nbytes)]
+        return host[:int(nbytes)], (lambda: None)
+
+
+def test_pipeline_side_batches_keep_off_the_chunk_ring(tmp_path, golden_integration, monkeypatch):
+    """A chunk's object-path loci (gzip, duplicate ids) are built on the same backend while the output stage and the writers may
+    still read the pinned text / tree-export buffers of the two previous chunks: their copies must use buffers of their own
+    (ring 1: download groups >= 4), and the main ring advances exactly once per chunk and group."""
+    import gzip
+    from make_prg_amd import pipeline
+    d = tmp_path / "in"
+    d.mkdir()
+    case = next(c for c in golden_integration["cases"] if c["case"] == "several")
+    n = 0
+    for rep in range(3):
+        for l in case["loci"]:
+            name = f"r{rep}_{l['file'].replace('.gz', '')}"
+            if n % 3 == 1:
+                with gzip.open(d / (name + ".gz"), "wt") as fh:
+                    fh.write(l["fasta"])
+            else:
+                (d / name).write_text(l["fasta"])
+            n += 1
+    monkeypatch.setenv("MPRG_PIPELINE", "1")
+    monkeypatch.setattr(pipeline, "CHUNK", 3)
+    be = _RingEmuBackend()
+    o = options(d, tmp_path / "out" / "x")
+    o.threads = 2
+    from_msa.run(o, backend=be)
+    files = sorted(d.iterdir(), key=pipeline.sort_key)
+    n_chunks = sum(any(not f.name.endswith(".gz") for f in files[lo:lo + 3]) for lo in range(0, len(files), 3))   # chunks with arena files
+    main = [g for g in be.log if g < 4]
+    assert any(g >= 4 for g in be.log), "the gzip files of a chunk go through the object path"
+    assert n_chunks >= 3 and all(main.count(g) == n_chunks for g in range(4)), (main, n_chunks)
+    # and the run is what the object path writes
+    monkeypatch.setenv("MPRG_PIPELINE", "0")
+    from_msa.run(options(d, tmp_path / "ref" / "x"), backend=EmuBackend())
+    assert (tmp_path / "out" / "x.prg.fa").read_bytes() == (tmp_path / "ref" / "x.prg.fa").read_bytes()
+    for kind in ("bin", "gfa"):
+        with zipfile.ZipFile(tmp_path / "out" / f"x.prg.{kind}.zip") as za, zipfile.ZipFile(tmp_path / "ref" / f"x.prg.{kind}.zip") as zb:
+            assert za.testzip() is None
+            loci = [pipeline.sort_key(f)[:-len(".prg.fa")] for f in files]
+            assert za.namelist() == [f"{l}.{kind}" for l in loci], "members in the run's locus order, object-path loci included"
+            assert {m: za.read(m) for m in za.namelist()} == {m: zb.read(m) for m in zb.namelist()}

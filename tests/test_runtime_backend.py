@@ -88,3 +88,41 @@ def test_every_thread_is_switched_to_the_backends_device(rt):
         assert len(calls) == 1
     finally:
         rt.lib.mprg_rt_init = real
+
+
+def test_close_and_regrowth_release_what_the_backend_owns():
+    """close() hands free-list blocks, page-locked blocks and streams back; a pinned upload buffer that is outgrown is released
+    at once, an outgrown download buffer only after its ring has gone round (a reader may still hold it); one header block
+    per backend, not per engine."""
+    be = HipRuntimeBackend(lib_path=build_emu())
+    freed, hfreed = [], []
+    real_free, real_hfree = be.lib.mprg_rt_free, be.lib.mprg_rt_host_free
+    be.lib.mprg_rt_free = lambda a: (freed.append(a), real_free(a))[1]
+    be.lib.mprg_rt_host_free = lambda a: (hfreed.append(a), real_hfree(a))[1]
+    try:
+        hb, _ = be.pinned(1 << 20, "arena")
+        first = hb.mprg_addr
+        hb2, arr2 = be.pinned(4 << 20, "arena")                 # outgrown: the old block goes
+        assert hfreed == [first] and hb2.mprg_addr != first and arr2.size >= 4 << 20
+        assert be.host_visible(768)[0] is be.host_visible(768)[0]
+        be.async_depth = 2
+        d = be.upload(np.arange(4 << 18, dtype=np.int64))
+        small, _ = be.download_async(d, 1 << 10, group=0)
+        old = small.ctypes.data
+        n_h = len(hfreed)
+        big, _ = be.download_async(d, 2 << 20, group=0)          # both ring buffers replaced; the old ones may still be read
+        assert len(hfreed) == n_h and small[0] == 0
+        be.download_async(d, 2 << 20, group=0)
+        assert len(hfreed) == n_h
+        be.download_async(d, 2 << 20, group=0)                   # the ring has gone round: now they are un-pinned
+        assert len(hfreed) == n_h + 2 and old in hfreed
+        a = be.empty(123456)
+        addr = a.mprg_addr
+        del a
+        n_host = len(be._host)
+        assert n_host >= 4
+        be.close()
+        assert addr in freed and len(hfreed) == n_h + 2 + n_host and be._host == [] and be.stream is None
+        be.close()                                               # idempotent
+    finally:
+        be.lib.mprg_rt_free, be.lib.mprg_rt_host_free = real_free, real_hfree
