@@ -245,6 +245,29 @@ int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32
                          int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, const int32_t *kinfo,
                          void *stream);
 
+/* A11 + A10 + A12 as ONE launch per workgroup form — cluster_sequences.py:256-274, the whole loop
+ *     while cluster_further(...): num_clusters += 1; KMeans(num_clusters).fit(X).predict(X); accept / revert
+ * of every problem: a problem's workgroup walks k = 2, 3, ... itself (fit = the bodies of mprg_kmeans_fit / _fit_small, best
+ * restart + predict, cluster_further on the view's dense gapped copy, the reference's rules: fewer than k distinct labels ->
+ * revert to k - 1 and stop; every cluster one-reference-like -> accept and stop; k > 10 or k == D -> stop), so a recursion
+ * level costs one launch per form instead of ~4 launches per round k — the launch tails that decide small batches.
+ * prob / xcounts / ws as for mprg_kmeans_fit (mprg_kmeans_prepare must have run); views = the problems' view table (prob[VIEW]),
+ * d_of_row / gcodes from mprg_ungap_dedupe (gcodes is required), scratch as for mprg_cluster_further (3 int32 per column of the
+ * views).  uniform_offsets_host: HOST array of 11 int32, [k] = offset (doubles) of k's uniforms in uniforms_dev, k = 2..10.
+ * In/out per problem: num_clusters (start: 1), active (start: 1; 0 afterwards unless a later form must continue), labels /
+ * assign (assign = labels of the last ACCEPTED fit), km_info / km_status of the problem's last fit.
+ * stats (device int64[96], accumulated): 80 fits run, 85 / 93 algorithmic bytes 8 D V (iterations + n_init) of the fits run in the
+ * general / small form (doubles), 84 cells visited by cluster_further (double), 82 set if a fit reported MPRG_KM_UNSUPPORTED.
+ * forms: which workgroup forms this call launches, in this order on `stream`: MPRG_LOOP_GENERAL (256 threads; with
+ * MPRG_LOOP_SKIP_SMALL it leaves the problems mprg_kmeans_small_class accepts to the small form), MPRG_LOOP_SMALL_LOW (128
+ * threads, k = 2..6), MPRG_LOOP_SMALL_HIGH (128 threads, continues the small problems still active with k = 7..10; must follow
+ * _LOW on the same stream).  The general and the small launches are independent: a host may put them on different streams. */
+enum { MPRG_LOOP_GENERAL = 1, MPRG_LOOP_SMALL_LOW = 2, MPRG_LOOP_SMALL_HIGH = 4, MPRG_LOOP_SKIP_SMALL = 8 };
+int mprg_cluster_loop(const int64_t *views, const int64_t *prob, int n_probs, int n_init, const double *uniforms_dev,
+                      const int32_t *uniform_offsets_host, const double *xcounts, double *ws, const int32_t *d_of_row,
+                      const uint8_t *gcodes, int32_t *scratch, int32_t *labels, int32_t *assign, double *km_info, int32_t *km_status,
+                      int32_t *num_clusters, int32_t *active, int64_t *stats, int forms, void *stream);
+
 /* A12/A14 — cluster_sequences.py:287-296 + recursion_tree.py:558-572: row lists of the children of MultiClusterNodes.
  * split_info: n_probs x 3 int64 {number of KMeans clusters, offset of the problem's n_rows entries in pool_out,
  * offset of its child sizes in child_sizes}.  Children order: the cluster holding the first row, then the KMeans

@@ -42,6 +42,7 @@ SIGNATURES = {
     "mprg_kmeans_fit_small": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7),
     "mprg_kmeans_select": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 5),
     "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int] + [c_void_p] * 6),
+    "mprg_cluster_loop": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 14 + [c_int, c_void_p]),
     "mprg_split_children": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 7),
     "mprg_leaf_jobs": (c_int, [c_void_p, c_int64] + [c_void_p] * 6),
     "mprg_emit_alleles": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
@@ -134,16 +135,18 @@ class _Base:
     profile = None   # set to a dict to collect per-entry-point device time (HIP events on the launch stream)
     profile_only = None   # optional set of entry points to time (None: all of them)
 
-    def call(self, name, *args, work: float = 0.0, side: Optional[int] = None):
+    def call(self, name, *args, work: float = 0.0, side: Optional[int] = None, label: Optional[str] = None):
         """Enqueue one C-ABI entry point.  `work` = algorithmic bytes of this launch (roofline accounting).  side: the launch
-        goes to side stream `side` (its stream argument must be side_ptr(side)): the timing events are recorded there."""
-        ev = self._event_pair() if self.profile is not None and (self.profile_only is None or name in self.profile_only) else None
+        goes to side stream `side` (its stream argument must be side_ptr(side)): the timing events are recorded there.
+        label: the name the launch is timed under (an entry point that launches different kernels by argument), default: name."""
+        key = label or name
+        ev = self._event_pair() if self.profile is not None and (self.profile_only is None or key in self.profile_only) else None
         if ev:
             self._record(ev[0], side)
         rc = getattr(self.lib, name)(*args)
         if ev:
             self._record(ev[1], side)
-            self.profile.setdefault(name, []).append((ev[0], ev[1], float(work)))
+            self.profile.setdefault(key, []).append((ev[0], ev[1], float(work)))
         if rc != 0:
             raise MprgError(f"{name} failed ({rc}): {self.lib.mprg_last_error().decode()}")
 
@@ -421,9 +424,9 @@ class HipRuntimeBackend(_Base):
             self._check(self.lib.mprg_rt_init(self.device), "device")
             _rt_thread.device = self.device
 
-    def call(self, name, *args, work: float = 0.0, side: Optional[int] = None):
+    def call(self, name, *args, work: float = 0.0, side: Optional[int] = None, label: Optional[str] = None):
         self._on_device()
-        return super().call(name, *args, work=work, side=side)
+        return super().call(name, *args, work=work, side=side, label=label)
 
     def _ptr(self, p, what):
         if not p:

@@ -12,6 +12,7 @@
 #include "k_kmer.inc"
 #include "k_kmeans.inc"
 #include "k_cluster.inc"
+#include "k_kloop.inc"
 #include "k_emit.inc"
 #include "k_forest.inc"
 #include "host_encoders.inc"
@@ -285,6 +286,29 @@ int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32
   LAUNCH(k_cluster_hamming, n_work_rows, CF_TILE, stream, arena, views, rowidx, prob, work_rows, d_of_row, labels,
          (const int32_t *)scratch, out_further, gcodes, kinfo);
   return check_launch("k_cluster_further");
+}
+
+int mprg_cluster_loop(const int64_t *views, const int64_t *prob, int n_probs, int n_init, const double *uniforms_dev,
+                      const int32_t *uniform_offsets_host, const double *xcounts, double *ws, const int32_t *d_of_row,
+                      const uint8_t *gcodes, int32_t *scratch, int32_t *labels, int32_t *assign, double *km_info, int32_t *km_status,
+                      int32_t *num_clusters, int32_t *active, int64_t *stats, int forms, void *stream) {
+  if (n_probs <= 0) return 0;
+  if (n_init < 1 || n_init > KM_RMAX) return fail("n_init must be 1..16");
+  if (!gcodes || !uniform_offsets_host || !stats) return fail("mprg_cluster_loop: gcodes, uniform_offsets_host and stats are required");
+  if (!(forms & 7)) return fail("mprg_cluster_loop: forms must name a workgroup form (MPRG_LOOP_*)");
+  KlUoff uoff;
+  for (int k = 0; k <= KM_KMAX; ++k) uoff.v[k] = k >= 2 ? uniform_offsets_host[k] : 0;
+  const bool small_ok = n_init <= KMS_RMAX;
+  if (forms & MPRG_LOOP_GENERAL)
+    LAUNCH(k_cluster_loop, n_probs, g_km_threads, stream, prob, n_init, uniforms_dev, uoff, xcounts, ws, views, d_of_row, gcodes, scratch, labels,
+           assign, km_info, km_status, num_clusters, active, stats, (forms & MPRG_LOOP_SKIP_SMALL) && small_ok ? 1 : 0);
+#define KLS_LAUNCH(KCH, KHI) hipLaunchKernelGGL((k_cluster_loop_small<KCH, KHI>), dim3((unsigned)n_probs), dim3(128), 0, (hipStream_t)stream, prob, \
+                                                 n_init, uniforms_dev, uoff, xcounts, ws, views, d_of_row, gcodes, scratch, labels, assign, \
+                                                 km_info, km_status, num_clusters, active, stats)
+  if ((forms & MPRG_LOOP_SMALL_LOW) && small_ok) KLS_LAUNCH(36, 6);
+  if ((forms & MPRG_LOOP_SMALL_HIGH) && small_ok) KLS_LAUNCH(KM_KMAX * KM_KMAX, KM_KMAX);
+#undef KLS_LAUNCH
+  return check_launch("k_cluster_loop");
 }
 
 int mprg_split_children(const int64_t *views, const int32_t *rowidx, const int64_t *prob, int n_probs,

@@ -52,6 +52,10 @@ KM_SIDE_STREAMS = os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0"
 # a launch list of at most this many fits goes through the SPLIT form (a workgroup per restart + a selection launch,
 # mprg_kmeans_fit_split): such a launch lasts one fit latency whatever it holds (profiles/r03/kmeans_split.md); 0 = never
 KM_SPLIT_BELOW = int(os.environ.get("MPRG_KM_SPLIT_BELOW", "0"))
+# the clustering loop: "fused" = a problem's workgroup walks k = 2..10 itself (mprg_cluster_loop; one launch per workgroup form and
+# level), "rounds" = one set of launches per round k (the shape of rounds 1-3)
+KLOOP_FUSED = os.environ.get("MPRG_KLOOP", "fused") != "rounds"
+LOOP_GENERAL, LOOP_SMALL = "mprg_cluster_loop[general]", "mprg_cluster_loop[small]"          # names the fused launches are timed under
 F_FIELDS = 96
 PREPARE_CLASSES = 4                      # LDS classes of mprg_kmeans_prepare (+ the global-memory form)
 
@@ -153,7 +157,7 @@ class ForestEngine(BatchEngine):
                   FUSED_ENABLED=int(FUSED_VIEWS), N_INIT=N_INIT, HDR=self.d_hdr, HDR_HOST=self._hdr_buf)
         for k_, o_ in uoff.items():
             self.F[FI["UOFF"] + k_] = o_
-        self._d_uni = d_uni
+        self._d_uni, self._uoff = d_uni, uoff
         f0, n = 0, len(ok)
         while n:
             self.counters["levels"] += 1
@@ -291,9 +295,78 @@ class ForestEngine(BatchEngine):
                 be.call("mprg_kmeans_prepare", be.ptr(d_ptab), n_c, be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, lst, n_c, be.stream, work=prep_work)
             prep_work = 0.0
         self.counters["launches"] += 3
-        # ---- S6: cluster_sequences.py:256-274 for all problems of the level, one k per round, no host decision in between:
-        #      the control step settles the previous round on the device; a retired problem's workgroups return at once
+        # ---- S6: cluster_sequences.py:256-274, the whole `while cluster_further: k += 1; KMeans(k)` loop of every problem inside the
+        #      problem's own workgroup (mprg_cluster_loop): one launch per workgroup form for the level, no control step, header or
+        #      host wait per round.  The general form and the small forms are independent launches: side by side on a side stream.
+        #      MPRG_KLOOP=rounds keeps the per-round launches of rounds 1-3 (k_kl_advance + fit lists + mprg_cluster_further).
         km_events, cf_events = [], []
+        if KLOOP_FUSED:
+            uoffs = np.zeros(MAX_CLUSTERS + 1, np.int32)
+            for k_, o_ in self._uoff.items():
+                uoffs[k_] = o_
+            small = bool(KM_MODE & 2)
+            loop_args = (be.ptr(d_sub), be.ptr(d_ptab), P, N_INIT, be.ptr(self._d_uni), uoffs.ctypes.data, be.ptr(d_x), be.ptr(d_ws),
+                         be.ptr(dd["d_of_row"]), be.ptr(dd["gcodes"]), be.ptr(d_scratch), be.ptr(d_labels), be.ptr(d_assign), be.ptr(d_info),
+                         be.ptr(d_st), be.ptr(d_numcl), be.ptr(d_active), be.ptr(self.d_hdr))
+            side = small and KM_SIDE_STREAMS and be.profile is None and be.n_side_streams >= 1
+            if side:
+                be.fork(1)
+            be.call("mprg_cluster_loop", *loop_args, 1 | (8 if small else 0), be.stream, label=LOOP_GENERAL)
+            ev = self._last_event(LOOP_GENERAL)
+            km_events.append(ev and ev + (LOOP_GENERAL,))
+            if small:
+                be.call("mprg_cluster_loop", *loop_args, 2 | 4, be.side_ptr(0) if side else be.stream, side=0 if side else None, label=LOOP_SMALL)
+                ev = self._last_event(LOOP_SMALL)
+                km_events.append(ev and ev + (LOOP_SMALL,))
+            if side:
+                be.join(1)
+            self.counters["launches"] += 2 if small else 1
+        else:
+            self._kloop_rounds(P, d_sub, d_ptab, d_kinfo, d_x, d_ws, d_labels, d_assign, d_info, d_st, d_wc, n_wc, d_wr, n_wr, d_scratch,
+                               d_further, dd, km_events, cf_events)
+        # ---- S7: MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
+        self._scratch(P)
+        h = self._step("splits_count", n_hdr=HDR)
+        n_splits, rows_sp, n_child = (int(x) for x in h[:3])
+        fits, cf_cells = int(h[80]), float(h[84:85].view(np.float64)[0])
+        kb = {"mprg_kmeans_fit_wave": float(h[81:82].view(np.float64)[0]), "mprg_kmeans_fit": float(h[85:86].view(np.float64)[0]),
+              "mprg_kmeans_fit_small": float(h[93:94].view(np.float64)[0])}
+        km_bytes = sum(kb.values())
+        if KLOOP_FUSED:          # a fused launch's algorithmic bytes: its fits' 8 D V (iterations + n_init) + the cells its cluster_further visits
+            kb = {LOOP_GENERAL: kb["mprg_kmeans_fit"], LOOP_SMALL: kb["mprg_kmeans_fit_small"]}
+            kb[LOOP_SMALL if (KM_MODE & 2) else LOOP_GENERAL] += cf_cells
+        if h[82]:
+            raise MprgError("KMeans empty-cluster relocation: the selection ran out of frames (more than 5^10 samples in a fit)")
+        self.counters["fits"] += fits
+        self.counters["kmeans_bytes"] += km_bytes
+        # algorithmic bytes are known only after the fits: 8 D V (iterations + n_init)
+        for entry, nbytes in kb.items():
+            self._credit([e[:2] for e in km_events if e and e[2] == entry], nbytes)
+        self._credit(cf_events, cf_cells)
+        if n_splits == 0:
+            return 0
+        self._pool_reserve(rows_sp)
+        d_spt, d_sp, d_splitnode, d_sizes = be.empty(8 * PF * n_splits), be.empty(24 * n_splits), be.empty(8 * n_splits), be.empty(4 * n_child)
+        self._set(SPT=d_spt, SP=d_sp, SPLITNODE=d_splitnode, CHILD_SIZES=d_sizes, NSPLITS=n_splits, POOL_USED=self.pool_used)
+        self._step("splits_fill")
+        # rowidx (parents' lists) and pool_out (children's lists) are the same pool, disjoint regions
+        be.call("mprg_split_children", be.ptr(d_sub), be.ptr(self.d_pool), be.ptr(d_spt), n_splits, be.ptr(d_sp),
+                be.ptr(dd["d_of_row"]), be.ptr(dd["s_of_row"]), be.ptr(d_assign), be.ptr(self.d_pool), be.ptr(d_sizes), be.stream)
+        self.counters["launches"] += 1
+        self._grow_nodes(self.n_nodes + n_child)
+        self._set(N_NODES=self.n_nodes)
+        self._step("split_children")
+        self.pool_used += rows_sp
+        self.n_nodes += n_child
+        self._set(POOL_USED=self.pool_used)
+        return n_child
+
+
+    def _kloop_rounds(self, P, d_sub, d_ptab, d_kinfo, d_x, d_ws, d_labels, d_assign, d_info, d_st, d_wc, n_wc, d_wr, n_wr, d_scratch,
+                      d_further, dd, km_events, cf_events):
+        """The clustering loop as one set of launches per round k (rounds 1-3's shape; MPRG_KLOOP=rounds): the control step settles
+        the previous round on the device (k_kl_advance), a retired problem's workgroups return at once."""
+        be = self.be
         d_fl = be.empty(4 * len(KM_LISTS) * P)
         self._set(FIT_LISTS=d_fl, KM_MODE=KM_MODE)
         fit_args = (be.ptr(self._d_uni), be.ptr(d_x), be.ptr(d_ws))
@@ -329,39 +402,6 @@ class ForestEngine(BatchEngine):
                 be.join(n_side)
             self._cluster_further(d_sub, d_ptab, P, k, dd, d_labels, d_assign, d_wc, n_wc, d_wr, n_wr, d_scratch, d_further, d_info, d_kinfo)
             cf_events.append(self._last_event("mprg_cluster_further"))
-        # ---- S7: MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
-        self._scratch(P)
-        h = self._step("splits_count", n_hdr=HDR)
-        n_splits, rows_sp, n_child = (int(x) for x in h[:3])
-        fits, cf_cells = int(h[80]), float(h[84:85].view(np.float64)[0])
-        kb = {"mprg_kmeans_fit_wave": float(h[81:82].view(np.float64)[0]), "mprg_kmeans_fit": float(h[85:86].view(np.float64)[0]),
-              "mprg_kmeans_fit_small": float(h[93:94].view(np.float64)[0])}
-        km_bytes = sum(kb.values())
-        if h[82]:
-            raise MprgError("KMeans empty-cluster relocation: the selection ran out of frames (more than 5^10 samples in a fit)")
-        self.counters["fits"] += fits
-        self.counters["kmeans_bytes"] += km_bytes
-        # algorithmic bytes are known only after the fits: 8 D V (iterations + n_init)
-        for entry, nbytes in kb.items():
-            self._credit([e[:2] for e in km_events if e and e[2] == entry], nbytes)
-        self._credit(cf_events, cf_cells)
-        if n_splits == 0:
-            return 0
-        self._pool_reserve(rows_sp)
-        d_spt, d_sp, d_splitnode, d_sizes = be.empty(8 * PF * n_splits), be.empty(24 * n_splits), be.empty(8 * n_splits), be.empty(4 * n_child)
-        self._set(SPT=d_spt, SP=d_sp, SPLITNODE=d_splitnode, CHILD_SIZES=d_sizes, NSPLITS=n_splits, POOL_USED=self.pool_used)
-        self._step("splits_fill")
-        # rowidx (parents' lists) and pool_out (children's lists) are the same pool, disjoint regions
-        be.call("mprg_split_children", be.ptr(d_sub), be.ptr(self.d_pool), be.ptr(d_spt), n_splits, be.ptr(d_sp),
-                be.ptr(dd["d_of_row"]), be.ptr(dd["s_of_row"]), be.ptr(d_assign), be.ptr(self.d_pool), be.ptr(d_sizes), be.stream)
-        self.counters["launches"] += 1
-        self._grow_nodes(self.n_nodes + n_child)
-        self._set(N_NODES=self.n_nodes)
-        self._step("split_children")
-        self.pool_used += rows_sp
-        self.n_nodes += n_child
-        self._set(POOL_USED=self.pool_used)
-        return n_child
 
     def _last_event(self, name):
         prof = self.be.profile
