@@ -1,5 +1,5 @@
 // mprg_api.hip — C ABI (include/mprg.h) over the gfx950 kernels of the from_msa hot path.
-// Build (product):  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared mprg_api.hip -o libmprg_hip.so
+// Build (product):  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -mllvm -disable-machine-licm -fPIC -shared mprg_api.hip -o libmprg_hip.so
 #include "mprg_platform.h"
 #include "../../include/mprg.h"
 #include <stdio.h>

@@ -94,3 +94,17 @@ def test_more_clusters_than_the_lds_offsets_of_split_children(emu, monkeypatch):
     text = "".join(f">s{i}\n{r}\n" for i, r in enumerate(rows))
     eng = pc.check_vs_oracle(emu, [text], 5, 7)
     assert np.bincount(eng.tab["parent"][eng.tab["parent"] >= 0]).max() > 1024      # a cluster node with > 1024 children
+
+
+def test_clustering_loop_forms_agree(monkeypatch, golden_integration):
+    """The fused loop's cluster_further has an in-LDS form (the view's cells fit the fit's pool) and a global-memory form with row
+    slices; the per-round launches of rounds 1-3 are a third way through the same decisions.  A test-only build forces the
+    global form; MPRG_KLOOP=rounds the per-round host: same answers as the oracle / the real reference's goldens."""
+    import make_prg_amd.forest as F
+    glob = EmuBackend(defines=("MPRG_TEST_CF_GLOBAL",), tag="_cfglobal")
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    pc.check_vs_oracle(glob, random_cases(41, 60), 5, 7)
+    assert pc.check_integration(glob, golden_integration) >= 30
+    monkeypatch.setattr(F, "KLOOP_FUSED", False)
+    pc.check_vs_oracle(EmuBackend(), random_cases(42, 40), 5, 7)
+    assert pc.check_integration(EmuBackend(), golden_integration) >= 30

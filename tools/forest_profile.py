@@ -39,6 +39,10 @@ for s in range(steps):
     print(f"step {s}: run_forest {1e3*(t1-t0):.1f} ms (downloads {1e3*d1['t']:.1f} ms in {d1['n']} waits), assemble {1e3*(t2-t1):.1f} ms "
           f"(downloads {1e3*(dl['t']-d1['t']):.1f} ms, {(dl['bytes']-d1['bytes'])/1e6:.1f} MB), nodes {eng.n_nodes}, levels {len(eng.levels)}, "
           f"calls {eng.counters['launches']}", flush=True)
+be.synchronize()
+for name, evs in be.profile.items():          # per launch: the clustering loop / KMeans launches of every level
+    if "cluster_loop" in name or "kmeans_fit" in name:
+        print(f"  per launch {name}: " + " ".join(f"{a.elapsed_time(b):.2f}" for a, b, _ in evs))
 prof = be.profile_summary()
 tot = sum(v["ms"] for v in prof.values())
 print(f"device time in entry points: {tot:.2f} ms")

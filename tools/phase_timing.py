@@ -18,6 +18,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "make_prg_amd", "_lib", "libmprg_hip_timing.so")
 msas = make_batch(list(range(n)), 16)[1]
 be = HipBackend(0, lib_path=lib)
+print('loop:', 'fused' if F.KLOOP_FUSED else 'rounds')
 eng = F.ForestEngine(be, 5, 7)
 eng.load(msas)
 eng.run_forest()
@@ -31,7 +32,8 @@ be.lib.mprg_debug_phase_cycles(out, 0)
 c = np.array(list(out), dtype=np.float64)
 names = ["k-means++ pick", "k-means++ score + first centres", "centre-centre distances", "sample-centre distances",
          "init bounds / E-step", "M-step", "relocation (slow path)", "shifts + norms", "bounds + stop test", "inertia",
-         "k-means++ first centre (pick of round 1)", "first centres copied + counts staged in LDS"]
+         "k-means++ first centre (pick of round 1)", "first centres copied + counts staged in LDS",
+         "fused loop: best restart + predict", "fused loop: cluster_further"]
 for nm, v in zip(names, c):
     print(f"{100 * v / c[:16].sum():6.1f} %  {nm}   ({v / max(eng.counters['fits'], 1):.0f} cycles per fit)")
 pn = ["gap runs (small views) / column flags (big views)", "serial scan", "pass A (N rows)", "pass B (row comparison)", "merge", "packed copy",
