@@ -340,8 +340,48 @@ enum {
   MPRG_F_EX_RECORDS = 84, MPRG_F_EX_ROWS = 85,
   MPRG_F_KM_MODE = 82 /* bit 0: small fits in the wave form, bit 1: small fits in the small workgroup form */,
   MPRG_F_HDR_HOST = 80 /* optional: host-visible (pinned) int64 [MPRG_FOREST_HDR]; every step that fills MPRG_F_HDR copies it there */,
-  MPRG_F_FIELDS = 96
+  /* mprg_forest_level only (below): the device state, the level's index, the buffers that the per-step hosts hand to the data entry
+   * points directly, and the CAPACITIES of the level's buffers */
+  MPRG_F_DS = 96, MPRG_F_LEVEL_INDEX = 97,
+  MPRG_F_MASK = 98, MPRG_F_MAXRUN = 99, MPRG_F_STACK = 100, MPRG_F_IVFLAG = 101, MPRG_F_IV = 102, MPRG_F_NIV = 103, MPRG_F_STATUS = 104,
+  MPRG_F_IVC = 105, MPRG_F_UCODES = 106, MPRG_F_GCODES = 107, MPRG_F_HASHES = 108, MPRG_F_ULEN = 109, MPRG_F_REP_U = 110, MPRG_F_REP_G = 111,
+  MPRG_F_D_OF_ROW = 112, MPRG_F_S_OF_ROW = 113, MPRG_F_REPS_POS = 114, MPRG_F_REPS_LEN = 115, MPRG_F_SEQROW = 116, MPRG_F_OCC_OFF = 117,
+  MPRG_F_CF_SCRATCH = 118, MPRG_F_TABLE = 119, MPRG_F_FLAG = 120, MPRG_F_X = 121, MPRG_F_WS = 122, MPRG_F_LABELS = 123, MPRG_F_ASSIGN = 124,
+  MPRG_F_UNIFORMS = 125, MPRG_F_UOFF_HOST = 126 /* HOST int32 [11] */, MPRG_F_LOOP_FORMS = 127 /* MPRG_LOOP_* */,
+  MPRG_F_CAP = 128 /* + MPRG_CAP_* */,
+  MPRG_F_FIELDS = 192
 };
+enum {
+  MPRG_CAP_TCOLS = 0 /* columns of the level's views */, MPRG_CAP_NFUSED = 1, MPRG_CAP_NOTHER = 2, MPRG_CAP_ITEMS = 3 /* mask work items at MPRG_F_RPC_IDX */,
+  MPRG_CAP_NGAP = 4, MPRG_CAP_NODES = 5 /* rows of the node table */, MPRG_CAP_SROWS = 6 /* rows of the selected views */,
+  MPRG_CAP_UBYTES = 7, MPRG_CAP_SCOLS = 8, MPRG_CAP_NDD = 9, MPRG_CAP_WC = 10, MPRG_CAP_WR = 11 /* work items of the k = 1 check */,
+  MPRG_CAP_TABLE = 12, MPRG_CAP_FLAG = 13, MPRG_CAP_LO = 14, MPRG_CAP_XD = 15, MPRG_CAP_WSD = 16, MPRG_CAP_CLS = 17 /* .. 21: problems per
+  mprg_kmeans_prepare class */, MPRG_CAP_LDS = 22 /* .. 25: LDS bytes each LDS class is launched with */, MPRG_CAP_NCHILD = 26,
+  MPRG_CAP_POOL = 27 /* entries of the row pool */
+};
+/* ---- a recursion level WITHOUT a host wait.  mprg_forest_level enqueues every step of one level — S1 .. S7 below and the data entry
+ * points between them (mprg_column_masks, mprg_partition, mprg_ungap_dedupe, mprg_cluster_further (k = 1), mprg_kmer_dictionary,
+ * mprg_kmer_counts, mprg_kmeans_prepare, mprg_cluster_loop, mprg_split_children) — on `stream` and returns; no total is read back.
+ * The host sizes the level's buffers from CAPACITIES it chooses (what the same level of a previous forest needed, plus headroom)
+ * and passes them where the per-step entry points take exact counts: MPRG_F_N, _N_VIEWS, _NSEL, _NPQ, _P, _NSPLITS and
+ * MPRG_F_CAP + MPRG_CAP_*.  Every launch is sized by its capacity; the exact counts are words of the device state that the count
+ * steps write, workgroups and items beyond them return at once.  A total that exceeds its capacity sets ds[MPRG_DS_OVERFLOW]
+ * (sticky) BEFORE anything is written beyond a buffer, and every later kernel of the forest returns at once: the host, which
+ * looks at the device state once after the last level, then repeats the forest with the per-step entry points (exact sizes).
+ * Device state MPRG_F_DS: int64 [MPRG_DS_GLOBAL + levels * MPRG_DS_LEVEL_WORDS], zeroed by the host, then ds[MPRG_DS_N] =
+ * ds[MPRG_DS_NNODES] = number of roots.  Level l (MPRG_F_LEVEL_INDEX, counted by the host) owns six step blocks of
+ * MPRG_FOREST_HDR words — block s at MPRG_DS_GLOBAL + (6 l + s) * MPRG_FOREST_HDR — that receive what the steps' headers hold
+ * in the per-step form (frontier block: words 13 / 14 = first node / nodes of the level's frontier; sizes block: the
+ * mprg_cluster_loop statistics, words 80 ..).  Buffers that must arrive zeroed: MPRG_F_MASK, _MAXRUN, _IVFLAG, _IVC, _X, _ASSIGN,
+ * _KM_STATUS.  The clustering loop is the fused one (mprg_cluster_loop, forms MPRG_F_LOOP_FORMS). */
+enum { MPRG_DS_OVERFLOW = 0 /* 0, or 100 * (level + 1) + the step whose totals did not fit */, MPRG_DS_F0 = 1, MPRG_DS_N = 2,
+       MPRG_DS_NNODES = 3, MPRG_DS_POOL_USED = 4, MPRG_DS_LEVEL = 5 /* levels enqueued so far */,
+       MPRG_DS_NFAILED = 6 /* set when a view's partition failed (its locus is dropped: MPRG_F_FAILED, MPRG_F_ERR_FIRST) */, MPRG_DS_GLOBAL = 16,
+       MPRG_DS_LEVEL_WORDS = 6 * 96 };
+enum { MPRG_STEP_FRONTIER = 0, MPRG_STEP_CLASSIFY = 1, MPRG_STEP_CLUSTER = 2, MPRG_STEP_PROBLEMS = 3, MPRG_STEP_SIZES = 4, MPRG_STEP_SPLITS = 5 };
+int mprg_forest_level(const int64_t *F, void *stream);
+/* zeroes the device state (n_words int64) and sets the forest's roots: ds[MPRG_DS_N] = ds[MPRG_DS_NNODES] = n_roots */
+int mprg_forest_state_init(int64_t *ds, long long n_words, long long n_roots, void *stream);
 /* S1  frontier -> views.  hdr: 0 views, 1 their columns, 2 their rows, 3 fused views, 4 other views, 5-9 mask work items for
  *     row chunks of 1024/512/256/128/64 rows, 10 gap-run row chunks, 11 cells, 12 cells of the other views.  The host picks MPRG_F_RPC_IDX from 5-9, allocates
  *     and calls _fill: views, view2node, fused / other lists, work items of mprg_column_masks and mprg_partition. */

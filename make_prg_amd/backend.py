@@ -46,6 +46,8 @@ SIGNATURES = {
     "mprg_split_children": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 7),
     "mprg_leaf_jobs": (c_int, [c_void_p, c_int64] + [c_void_p] * 6),
     "mprg_emit_alleles": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mprg_forest_level": (c_int, [c_void_p, c_void_p]),
+    "mprg_forest_state_init": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_longlong, c_void_p]),
     "mprg_forest_frontier_count": (c_int, [c_void_p, c_void_p]),
     "mprg_forest_frontier_fill": (c_int, [c_void_p, c_void_p]),
     "mprg_forest_classify": (c_int, [c_void_p, c_void_p]),
@@ -220,6 +222,9 @@ class HipBackend(_Base):
 
     def zeros(self, nbytes: int):
         return self.torch.zeros(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
+
+    def full(self, nbytes: int, byte: int):
+        return self.torch.full((max(int(nbytes), 16),), int(byte), dtype=self.torch.uint8, device=self.device)
 
     def upload(self, arr: np.ndarray):
         arr = np.ascontiguousarray(arr)
@@ -653,9 +658,12 @@ class HipRuntimeBackend(_Base):
             self.lib.mprg_rt_stream_wait_event(self.stream, ev.h)
 
     def zeros(self, nbytes: int):
+        return self.full(nbytes, 0)
+
+    def full(self, nbytes: int, byte: int):
         buf = self.empty(nbytes)
         self._on_device()
-        self._check(self.lib.mprg_rt_memset_async(buf.mprg_addr, 0, buf.nbytes, self.stream), "memset")
+        self._check(self.lib.mprg_rt_memset_async(buf.mprg_addr, int(byte), buf.nbytes, self.stream), "memset")
         return buf
 
 

@@ -3,6 +3,7 @@
 #include "mprg_platform.h"
 #include "../../include/mprg.h"
 #include <stdio.h>
+#include <initializer_list>
 #include <string.h>
 
 #include "k_ingest.inc"
@@ -72,12 +73,17 @@ int mprg_column_residue_counts(const uint8_t *raw, const int64_t *table, const i
   return check_launch("k_column_residue_counts");
 }
 
-int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int32_t *work,
-                      int n_items, int rows_per_chunk, uint32_t *out_mask, void *stream) {
+// (the d_* forms: an entry point's launches with optional device-side counts — DsCount, mprg_platform.h; mprg_forest_level uses them)
+static int d_column_masks(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int32_t *work,
+                          int n_items, int rows_per_chunk, uint32_t *out_mask, void *stream, DsCount dc) {
   if (n_items <= 0) return 0;
   if (rows_per_chunk <= 0) return fail("rows_per_chunk must be positive");
-  LAUNCH(k_column_masks, n_items, CM_THREADS, stream, arena, views, rowidx, work, rows_per_chunk, out_mask);
+  LAUNCH(k_column_masks, n_items, CM_THREADS, stream, arena, views, rowidx, work, rows_per_chunk, out_mask, dc);
   return check_launch("k_column_masks");
+}
+int mprg_column_masks(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int32_t *work,
+                      int n_items, int rows_per_chunk, uint32_t *out_mask, void *stream) {
+  return d_column_masks(arena, views, rowidx, work, n_items, rows_per_chunk, out_mask, stream, DS_HOST);
 }
 
 int mprg_compact_columns(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int32_t *work, int n_items,
@@ -88,41 +94,64 @@ int mprg_compact_columns(const uint8_t *arena, const int64_t *views, const int32
   return check_launch("k_compact_columns");
 }
 
+static int d_partition(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
+                       const uint32_t *mask, int min_match_length, const int32_t *work_rows, int n_work_rows,
+                       uint32_t *maxrun, int32_t *stack, int32_t *ivflag, int32_t *iv, int32_t *n_iv, int32_t *status,
+                       int32_t *view_out, int32_t *iv_packed, int32_t *iv_count, const int32_t *fused_list, int n_fused,
+                       const int32_t *other_list, int n_other, void *stream, DsCount dc_views, DsCount dc_rows, DsCount dc_fused,
+                       DsCount dc_other);
 int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
                    const uint32_t *mask, int min_match_length, const int32_t *work_rows, int n_work_rows,
                    uint32_t *maxrun, int32_t *stack, int32_t *ivflag, int32_t *iv, int32_t *n_iv, int32_t *status,
                    int32_t *view_out, int32_t *iv_packed, int32_t *iv_count, const int32_t *fused_list, int n_fused,
                    const int32_t *other_list, int n_other, void *stream) {
+  return d_partition(arena, views, rowidx, n_views, mask, min_match_length, work_rows, n_work_rows, maxrun, stack, ivflag, iv, n_iv, status,
+                     view_out, iv_packed, iv_count, fused_list, n_fused, other_list, n_other, stream, DS_HOST, DS_HOST, DS_HOST, DS_HOST);
+}
+static int d_partition(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views,
+                       const uint32_t *mask, int min_match_length, const int32_t *work_rows, int n_work_rows,
+                       uint32_t *maxrun, int32_t *stack, int32_t *ivflag, int32_t *iv, int32_t *n_iv, int32_t *status,
+                       int32_t *view_out, int32_t *iv_packed, int32_t *iv_count, const int32_t *fused_list, int n_fused,
+                       const int32_t *other_list, int n_other, void *stream, DsCount dc_views, DsCount dc_rows, DsCount dc_fused,
+                       DsCount dc_other) {
   if (n_views <= 0) return 0;
   if (!fused_list && !other_list) { n_fused = 0; n_other = n_views; }
-  else if (n_fused < 0 || n_other < 0 || n_fused + n_other != n_views) return fail("mprg_partition: the two view lists must cover the views");
+  else if (n_fused < 0 || n_other < 0 || (!dc_views.ds && n_fused + n_other != n_views)) return fail("mprg_partition: the two view lists must cover the views");
   else if ((n_fused > 0 && !fused_list) || (n_other > 0 && !other_list)) return fail("mprg_partition: a view list is missing");
   if (min_match_length < 1) return fail("mprg_partition: min_match_length must be positive");
-  if (n_work_rows > 0) LAUNCH(k_gap_runs, n_work_rows, GR_ROWS, stream, arena, views, rowidx, work_rows, mask, maxrun);
+  if (n_work_rows > 0) LAUNCH(k_gap_runs, n_work_rows, GR_ROWS, stream, arena, views, rowidx, work_rows, mask, maxrun, dc_rows);
   if (n_other > 0)
     LAUNCH(k_partition, n_other, BLOCK_VIEW, stream, other_list, arena, views, rowidx, mask, min_match_length, maxrun, stack,
-           ivflag, iv, n_iv, status, view_out);
+           ivflag, iv, n_iv, status, view_out, dc_other);
   if (n_fused > 0)
     LAUNCH(k_partition_fused, n_fused, g_pf_threads, stream, fused_list, arena, views, rowidx, min_match_length, iv, n_iv, status,
-           view_out);
+           view_out, dc_fused);
   if (view_out) {                                  // the packed list of all triples of the call
     if (!iv_packed || !iv_count) return fail("mprg_partition: view_out needs iv_packed and iv_count");
-    LAUNCH(k_pack_scan, 1, 1024, stream, n_views, n_iv, view_out, iv_count);
+    LAUNCH(k_pack_scan, 1, 1024, stream, n_views, n_iv, view_out, iv_count, dc_views);
     LAUNCH(k_pack_copy, (n_views + PK_THREADS / WAVE - 1) / (PK_THREADS / WAVE), PK_THREADS, stream, n_views, views, iv, view_out,
-           iv_packed);
+           iv_packed, dc_views);
   }
   return check_launch("k_partition");
 }
 
+static int d_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views, int kmer_size,
+                          const int32_t *work_rows, int n_work_rows, uint8_t *ucodes, uint64_t *hashes, int32_t *ulen,
+                          int32_t *rep_u, int32_t *rep_g, int32_t *d_of_row, int32_t *s_of_row, int32_t *reps_pos,
+                          int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, uint8_t *gcodes, void *stream,
+                          DsCount dc_views, DsCount dc_rows) {
+  if (n_views <= 0) return 0;
+  if (n_work_rows > 0) LAUNCH(k_ungap_hash, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, ucodes, hashes, ulen, gcodes, dc_rows);
+  LAUNCH(k_ungap_dedupe, n_views, g_dd_threads, stream, arena, views, rowidx, kmer_size, ucodes, (const uint8_t *)gcodes, hashes, ulen, rep_u, rep_g,
+         d_of_row, s_of_row, reps_pos, reps_len, seqrow, occ_off, summary, dc_views);
+  return check_launch("k_ungap_dedupe");
+}
 int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views, int kmer_size,
                       const int32_t *work_rows, int n_work_rows, uint8_t *ucodes, uint64_t *hashes, int32_t *ulen,
                       int32_t *rep_u, int32_t *rep_g, int32_t *d_of_row, int32_t *s_of_row, int32_t *reps_pos,
                       int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, uint8_t *gcodes, void *stream) {
-  if (n_views <= 0) return 0;
-  LAUNCH(k_ungap_hash, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, ucodes, hashes, ulen, gcodes);
-  LAUNCH(k_ungap_dedupe, n_views, g_dd_threads, stream, arena, views, rowidx, kmer_size, ucodes, (const uint8_t *)gcodes, hashes, ulen, rep_u, rep_g,
-         d_of_row, s_of_row, reps_pos, reps_len, seqrow, occ_off, summary);
-  return check_launch("k_ungap_dedupe");
+  return d_ungap_dedupe(arena, views, rowidx, n_views, kmer_size, work_rows, n_work_rows, ucodes, hashes, ulen, rep_u, rep_g, d_of_row, s_of_row,
+                        reps_pos, reps_len, seqrow, occ_off, summary, gcodes, stream, DS_HOST, DS_HOST);
 }
 
 int mprg_kmer_dictionary(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size,
@@ -132,7 +161,7 @@ int mprg_kmer_dictionary(const int64_t *views, const int64_t *prob, int n_probs,
   if (n_probs <= 0) return 0;
   if (kmer_size < 1) return fail("k-mer size must be positive");
   LAUNCH(k_kmer_dictionary, n_probs, KD_THREADS, stream, views, prob, kmer_size, ucodes, seqrow, (const int64_t *)occ_off, table,
-         first_flag, out_V);
+         first_flag, out_V, DS_HOST);
   return check_launch("k_kmer_dictionary");
 }
 
@@ -142,7 +171,7 @@ int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int
   (void)ulen;
   if (n_probs <= 0) return 0;
   if (kmer_size < 1) return fail("k-mer size must be positive");
-  LAUNCH(k_kmer_counts, n_probs, 512, stream, views, prob, kmer_size, ucodes, seqrow, occ_off, table, xcounts);
+  LAUNCH(k_kmer_counts, n_probs, 512, stream, views, prob, kmer_size, ucodes, seqrow, occ_off, table, xcounts, DS_HOST);
   return check_launch("k_kmer_counts");
 }
 
@@ -151,15 +180,22 @@ int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_res
   return km_common_doubles_host(D, V) + (int64_t)n_restart_slots * km_restart_doubles_host(D, V);
 }
 
+static int d_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, const int32_t *lds_list,
+                            int n_lds, int64_t lds_bytes, const int32_t *other_list, int n_other, void *stream, DsCount dc);
 int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, const int32_t *lds_list,
                         int n_lds, int64_t lds_bytes, const int32_t *other_list, int n_other, void *stream) {
+  return d_kmeans_prepare(prob, n_probs, xcounts, ws, lds_list, n_lds, lds_bytes, other_list, n_other, stream, DS_HOST);
+}
+// dc: device count of the ONE list the call holds (device-counted calls pass either lds_list or other_list)
+static int d_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, const int32_t *lds_list,
+                            int n_lds, int64_t lds_bytes, const int32_t *other_list, int n_other, void *stream, DsCount dc) {
   if (n_probs <= 0) return 0;
   if (!lds_list && !other_list) { n_lds = 0; n_other = n_probs; }
   else if (n_lds + n_other != n_probs) return fail("mprg_kmeans_prepare: the two problem lists must cover the problems");
   if (n_lds > 0 && (lds_bytes <= 0 || lds_bytes > MPRG_KMEANS_PREPARE_LDS_MAX)) return fail("mprg_kmeans_prepare: lds_bytes out of range");
   if (n_other > 0) {
-    LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws);
-    LAUNCH(k_kmeans_prepare_tables, (long long)n_other * KP_PARTS, 256, stream, other_list, prob, xcounts, ws);
+    LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws, dc);
+    LAUNCH(k_kmeans_prepare_tables, (long long)n_other * KP_PARTS, 256, stream, other_list, prob, xcounts, ws, dc);
   }
   if (n_lds > 0) {
     if (lds_bytes > 64 * 1024) {     // beyond the default per-workgroup limit: gfx950 has 160 KB of LDS per CU, one such workgroup fits
@@ -173,7 +209,7 @@ int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts,
     }
     // LDS decides how many of these workgroups a CU holds: the big classes get the threads the small ones get from residency
     const int prep_threads = g_kp_threads ? g_kp_threads : (lds_bytes > 64 * 1024 ? 1024 : (lds_bytes > 24 * 1024 ? 512 : 256));
-    LAUNCH_LDS(k_kmeans_prepare_lds, n_lds, prep_threads, lds_bytes, stream, lds_list, prob, xcounts, ws);
+    LAUNCH_LDS(k_kmeans_prepare_lds, n_lds, prep_threads, lds_bytes, stream, lds_list, prob, xcounts, ws, dc);
   }
   return check_launch("k_kmeans_prepare");
 }
@@ -273,25 +309,49 @@ int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, in
   return check_launch("k_kmeans_select");
 }
 
+static int d_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
+                             int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
+                             const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
+                             int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, const int32_t *kinfo,
+                             void *stream, DsCount dc_cols, DsCount dc_rows);
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
                          int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                          const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
                          int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, const int32_t *kinfo,
                          void *stream) {
+  return d_cluster_further(arena, views, rowidx, prob, n_probs, k, d_of_row, labels, assign, work_cols, n_work_cols, work_rows, n_work_rows,
+                           scratch, out_further, km_info, gcodes, kinfo, stream, DS_HOST, DS_HOST);
+}
+static int d_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
+                             int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
+                             const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
+                             int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, const int32_t *kinfo,
+                             void *stream, DsCount dc_cols, DsCount dc_rows) {
   if (n_probs <= 0) return 0;
   if (k < 1 || k > KM_KMAX) return fail("mprg_cluster_further: k out of range");
   if (hipMemsetAsync(out_further, 0, sizeof(int32_t) * n_probs, (hipStream_t)stream) != hipSuccess) return fail("memset");
   LAUNCH(k_cluster_majority, n_work_cols, CF_THREADS, stream, arena, views, rowidx, prob, work_cols, k, d_of_row, labels,
-         assign, km_info, scratch, gcodes, kinfo);
+         assign, km_info, scratch, gcodes, kinfo, dc_cols);
   LAUNCH(k_cluster_hamming, n_work_rows, CF_TILE, stream, arena, views, rowidx, prob, work_rows, d_of_row, labels,
-         (const int32_t *)scratch, out_further, gcodes, kinfo);
+         (const int32_t *)scratch, out_further, gcodes, kinfo, dc_rows);
   return check_launch("k_cluster_further");
 }
 
+static int d_cluster_loop(const int64_t *views, const int64_t *prob, int n_probs, int n_init, const double *uniforms_dev,
+                          const int32_t *uniform_offsets_host, const double *xcounts, double *ws, const int32_t *d_of_row,
+                          const uint8_t *gcodes, int32_t *scratch, int32_t *labels, int32_t *assign, double *km_info, int32_t *km_status,
+                          int32_t *num_clusters, int32_t *active, int64_t *stats, int forms, void *stream, DsCount dc);
 int mprg_cluster_loop(const int64_t *views, const int64_t *prob, int n_probs, int n_init, const double *uniforms_dev,
                       const int32_t *uniform_offsets_host, const double *xcounts, double *ws, const int32_t *d_of_row,
                       const uint8_t *gcodes, int32_t *scratch, int32_t *labels, int32_t *assign, double *km_info, int32_t *km_status,
                       int32_t *num_clusters, int32_t *active, int64_t *stats, int forms, void *stream) {
+  return d_cluster_loop(views, prob, n_probs, n_init, uniforms_dev, uniform_offsets_host, xcounts, ws, d_of_row, gcodes, scratch, labels, assign,
+                        km_info, km_status, num_clusters, active, stats, forms, stream, DS_HOST);
+}
+static int d_cluster_loop(const int64_t *views, const int64_t *prob, int n_probs, int n_init, const double *uniforms_dev,
+                          const int32_t *uniform_offsets_host, const double *xcounts, double *ws, const int32_t *d_of_row,
+                          const uint8_t *gcodes, int32_t *scratch, int32_t *labels, int32_t *assign, double *km_info, int32_t *km_status,
+                          int32_t *num_clusters, int32_t *active, int64_t *stats, int forms, void *stream, DsCount dc) {
   if (n_probs <= 0) return 0;
   if (n_init < 1 || n_init > KM_RMAX) return fail("n_init must be 1..16");
   if (!gcodes || !uniform_offsets_host || !stats) return fail("mprg_cluster_loop: gcodes, uniform_offsets_host and stats are required");
@@ -301,10 +361,10 @@ int mprg_cluster_loop(const int64_t *views, const int64_t *prob, int n_probs, in
   const bool small_ok = n_init <= KMS_RMAX;
   if (forms & MPRG_LOOP_GENERAL)
     LAUNCH(k_cluster_loop, n_probs, g_km_threads, stream, prob, n_init, uniforms_dev, uoff, xcounts, ws, views, d_of_row, gcodes, scratch, labels,
-           assign, km_info, km_status, num_clusters, active, stats, (forms & MPRG_LOOP_SKIP_SMALL) && small_ok ? 1 : 0);
+           assign, km_info, km_status, num_clusters, active, stats, (forms & MPRG_LOOP_SKIP_SMALL) && small_ok ? 1 : 0, dc);
 #define KLS_LAUNCH(KCH, KHI) hipLaunchKernelGGL((k_cluster_loop_small<KCH, KHI>), dim3((unsigned)n_probs), dim3(128), 0, (hipStream_t)stream, prob, \
                                                  n_init, uniforms_dev, uoff, xcounts, ws, views, d_of_row, gcodes, scratch, labels, assign, \
-                                                 km_info, km_status, num_clusters, active, stats)
+                                                 km_info, km_status, num_clusters, active, stats, dc)
   if ((forms & MPRG_LOOP_SMALL_LOW) && small_ok) KLS_LAUNCH(36, 6);
   if ((forms & MPRG_LOOP_SMALL_HIGH) && small_ok) KLS_LAUNCH(KM_KMAX * KM_KMAX, KM_KMAX);
 #undef KLS_LAUNCH
@@ -316,7 +376,7 @@ int mprg_split_children(const int64_t *views, const int32_t *rowidx, const int64
                         const int32_t *assign, int32_t *pool_out, int32_t *child_sizes, void *stream) {
   if (n_probs <= 0) return 0;
   LAUNCH(k_split_children, n_probs, 64, stream, views, rowidx, prob, split_info, d_of_row, s_of_row, assign, pool_out,
-         child_sizes);
+         child_sizes, DS_HOST);
   return check_launch("k_split_children");
 }
 
@@ -340,86 +400,136 @@ static int kf_publish(const int64_t *F, void *stream, const char *name) {
   if (F[MPRG_F_HDR_HOST]) LAUNCH(k_hdr_publish, 1, 128, stream, (const int64_t *)FHDR, FP(int64_t, MPRG_F_HDR_HOST));
   return check_launch(name);
 }
-static int kf_count_done(const int64_t *F, long long n, int m, void *stream, const char *name) {
-  if (kf_scan(FP(int64_t, MPRG_F_VALS), n, m, FHDR, FP(int64_t, MPRG_F_SCAN_TMP), stream) != 0) return fail("scan");
-  return kf_publish(F, stream, name);
+// Every step exists once, for both ways of running a level: `ds` == nullptr — the step's own entry point, called by a host that
+// reads the totals back (hdr = MPRG_F_HDR, published to the host) — or the forest's device state — mprg_forest_level: the item
+// counts in F are CAPACITIES, the exact counts are words of ds, the step's totals go to its block `hdr` inside ds.
+struct KfStep { const int64_t *ds; int64_t *hdr; };
+static inline DsCount kf_dc(const KfStep &st, long long slot) { return DsCount{st.ds, (int)slot}; }
+static inline int kf_slot(const KfStep &st, const int64_t *word) { return st.ds ? (int)(word - st.ds) : 0; }
+static int kf_count_done(const int64_t *F, const KfStep &st, long long n, int m, DsCount dc, void *stream, const char *name) {
+  if (kf_scan(FP(int64_t, MPRG_F_VALS), n, m, st.hdr, FP(int64_t, MPRG_F_SCAN_TMP), stream, dc) != 0) return fail("scan");
+  return st.ds ? check_launch(name) : kf_publish(F, stream, name);
 }
-int mprg_forest_frontier_count(const int64_t *F, void *stream) {
+static int kf_frontier_count(const int64_t *F, const KfStep &st, void *stream) {
   const long long n = F[MPRG_F_N];
+  const DsCount dn = kf_dc(st, MPRG_DS_N);
   if (n > 0) LAUNCH(k_fr_count, KF_GRID(n), 256, stream, FP(const int64_t, MPRG_F_NODES), (long long)F[MPRG_F_F0], n, (int)F[MPRG_F_MIN_MATCH],
-                    (int)F[MPRG_F_FUSED_ENABLED], FP(int64_t, MPRG_F_VALS));
-  return kf_count_done(F, n, 13, stream, "k_fr_count");
+                    (int)F[MPRG_F_FUSED_ENABLED], FP(int64_t, MPRG_F_VALS), dn);
+  return kf_count_done(F, st, n, 13, dn, stream, "k_fr_count");
 }
-int mprg_forest_frontier_fill(const int64_t *F, void *stream) {
+static int kf_frontier_fill(const int64_t *F, const KfStep &st, void *stream) {
   const long long n = F[MPRG_F_N];
   if (n <= 0) return 0;
   LAUNCH(k_fr_fill, KF_GRID(n), 256, stream, FP(int64_t, MPRG_F_NODES), (long long)F[MPRG_F_F0], n, (int)F[MPRG_F_MIN_MATCH],
          (int)F[MPRG_F_FUSED_ENABLED], FP(const int64_t, MPRG_F_VALS), FP(const int64_t, MPRG_F_META), (int)F[MPRG_F_RPC_IDX],
          FP(int64_t, MPRG_F_VIEWS), FP(int64_t, MPRG_F_VIEW2NODE), FP(int32_t, MPRG_F_FUSED_LIST), FP(int32_t, MPRG_F_OTHER_LIST),
-         FP(int32_t, MPRG_F_MASK_WORK), FP(int32_t, MPRG_F_GAP_WORK));
+         FP(int32_t, MPRG_F_MASK_WORK), FP(int32_t, MPRG_F_GAP_WORK), kf_dc(st, MPRG_DS_N));
   return check_launch("k_fr_fill");
 }
-int mprg_forest_classify(const int64_t *F, void *stream) {
+// frontier: the frontier step's block (device counts of the views); null in the host-counted form
+static int kf_classify(const int64_t *F, const KfStep &st, const int64_t *frontier, void *stream) {
   const long long n = F[MPRG_F_N], nv = F[MPRG_F_N_VIEWS];
+  const DsCount dn = kf_dc(st, MPRG_DS_N);
   if (nv > 0) LAUNCH(k_lv_status, KF_GRID(nv), 256, stream, FP(const int64_t, MPRG_F_NODES), (long long)F[MPRG_F_F0], nv,
                      FP(const int64_t, MPRG_F_VIEW2NODE), FP(const int32_t, MPRG_F_VIEW_OUT), FP(int32_t, MPRG_F_FAILED),
-                     FP(int64_t, MPRG_F_ERR_FIRST));
+                     FP(int64_t, MPRG_F_ERR_FIRST), kf_dc(st, kf_slot(st, frontier)));
   if (n > 0) LAUNCH(k_lv_classify, KF_GRID(n), 256, stream, FP(int64_t, MPRG_F_NODES), (long long)F[MPRG_F_F0], n, (int)F[MPRG_F_LVL],
-                    FP(const int32_t, MPRG_F_VIEW_OUT), FP(const int32_t, MPRG_F_FAILED), FP(int64_t, MPRG_F_VALS));
-  return kf_count_done(F, n, 7, stream, "k_lv_classify");
+                    FP(const int32_t, MPRG_F_VIEW_OUT), FP(const int32_t, MPRG_F_FAILED), FP(int64_t, MPRG_F_VALS), dn);
+  return kf_count_done(F, st, n, 7, dn, stream, "k_lv_classify");
 }
-int mprg_forest_children(const int64_t *F, void *stream) {
+static int kf_children(const int64_t *F, const KfStep &st, void *stream) {
   const long long n = F[MPRG_F_N];
   if (n <= 0) return 0;
+  const DsCount dn = kf_dc(st, MPRG_DS_N);
   LAUNCH(k_lv_children, (n + 3) / 4, 256, stream, FP(int64_t, MPRG_F_NODES), (long long)F[MPRG_F_F0], n, (long long)F[MPRG_F_N_NODES],
-         FP(const int64_t, MPRG_F_VALS), FP(const int32_t, MPRG_F_VIEW_OUT), FP(const int32_t, MPRG_F_IV_PACKED));
+         FP(const int64_t, MPRG_F_VALS), FP(const int32_t, MPRG_F_VIEW_OUT), FP(const int32_t, MPRG_F_IV_PACKED), dn);
   if (F[MPRG_F_NSEL] > 0)
     LAUNCH(k_lv_sub, KF_GRID(n), 256, stream, FP(const int64_t, MPRG_F_NODES), (long long)F[MPRG_F_F0], n, FP(const int64_t, MPRG_F_VALS),
-           FP(const int64_t, MPRG_F_VIEWS), FP(int64_t, MPRG_F_SUB), FP(int64_t, MPRG_F_SELNODE), FP(int32_t, MPRG_F_DD_WORK));
+           FP(const int64_t, MPRG_F_VIEWS), FP(int64_t, MPRG_F_SUB), FP(int64_t, MPRG_F_SELNODE), FP(int32_t, MPRG_F_DD_WORK), dn);
   return check_launch("k_lv_children");
 }
-int mprg_forest_cluster_count(const int64_t *F, void *stream) {
+// n_sel: device count of the selected views (a word of the classify step's block)
+static int kf_cluster_count(const int64_t *F, const KfStep &st, const int64_t *n_sel, void *stream) {
   const long long n = F[MPRG_F_NSEL];
+  const DsCount dn = kf_dc(st, kf_slot(st, n_sel));
   if (n > 0) LAUNCH(k_cl_classify, KF_GRID(n), 256, stream, FP(int64_t, MPRG_F_NODES), n, FP(const int64_t, MPRG_F_SELNODE),
-                    FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_SUMMARY), (int)F[MPRG_F_MAX_NESTING], FP(int64_t, MPRG_F_VALS));
-  return kf_count_done(F, n, 5, stream, "k_cl_classify");
+                    FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_SUMMARY), (int)F[MPRG_F_MAX_NESTING], FP(int64_t, MPRG_F_VALS), dn);
+  return kf_count_done(F, st, n, 5, dn, stream, "k_cl_classify");
 }
-int mprg_forest_cluster_fill(const int64_t *F, void *stream) {
+static int kf_cluster_fill(const int64_t *F, const KfStep &st, const int64_t *n_sel, void *stream) {
   const long long n = F[MPRG_F_NSEL];
   if (n <= 0 || F[MPRG_F_NPQ] <= 0) return 0;
   LAUNCH(k_cl_fill_pq, KF_GRID(n), 256, stream, FP(const int64_t, MPRG_F_NODES), n, FP(const int64_t, MPRG_F_SELNODE),
          FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_SUMMARY), FP(const int64_t, MPRG_F_VALS), FP(int64_t, MPRG_F_T1),
-         FP(int32_t, MPRG_F_WORK_COLS), FP(int32_t, MPRG_F_WORK_ROWS));
+         FP(int32_t, MPRG_F_WORK_COLS), FP(int32_t, MPRG_F_WORK_ROWS), kf_dc(st, kf_slot(st, n_sel)));
   return check_launch("k_cl_fill_pq");
 }
-int mprg_forest_problems_count(const int64_t *F, void *stream) {
+static int kf_problems_count(const int64_t *F, const KfStep &st, const int64_t *n_pq, void *stream) {
   const long long n = F[MPRG_F_NPQ];
+  const DsCount dn = kf_dc(st, kf_slot(st, n_pq));
   if (n > 0) LAUNCH(k_pr_count, KF_GRID(n), 256, stream, n, FP(const int64_t, MPRG_F_T1), FP(const int32_t, MPRG_F_FURTHER),
-                    FP(const int64_t, MPRG_F_SUMMARY), FP(int64_t, MPRG_F_VALS));
-  return kf_count_done(F, n, 4, stream, "k_pr_count");
+                    FP(const int64_t, MPRG_F_SUMMARY), FP(int64_t, MPRG_F_VALS), dn);
+  return kf_count_done(F, st, n, 4, dn, stream, "k_pr_count");
 }
-int mprg_forest_problems_fill(const int64_t *F, void *stream) {
+static int kf_problems_fill(const int64_t *F, const KfStep &st, const int64_t *n_pq, void *stream) {
   const long long n = F[MPRG_F_NPQ];
   if (n <= 0 || F[MPRG_F_P] <= 0) return 0;
   LAUNCH(k_pr_fill, KF_GRID(n), 256, stream, n, FP(const int64_t, MPRG_F_T1), FP(const int32_t, MPRG_F_FURTHER),
-         FP(const int64_t, MPRG_F_SUMMARY), FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_VALS), FP(int64_t, MPRG_F_PTAB0));
+         FP(const int64_t, MPRG_F_SUMMARY), FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_VALS), FP(int64_t, MPRG_F_PTAB0),
+         kf_dc(st, kf_slot(st, n_pq)));
   return check_launch("k_pr_fill");
 }
-int mprg_forest_sizes_count(const int64_t *F, void *stream) {
+// n_p: device count of the problems (a word of the problems step's block)
+static int kf_sizes_count(const int64_t *F, const KfStep &st, const int64_t *n_p, void *stream) {
   const long long P = F[MPRG_F_P];
-  if (hipMemsetAsync(FHDR, 0, sizeof(int64_t) * MPRG_FOREST_HDR, (hipStream_t)stream) != hipSuccess) return fail("memset");
+  const DsCount dn = kf_dc(st, kf_slot(st, n_p));
+  if (hipMemsetAsync(st.hdr, 0, sizeof(int64_t) * MPRG_FOREST_HDR, (hipStream_t)stream) != hipSuccess) return fail("memset");
   if (P > 0) LAUNCH(k_sz_count, KF_GRID(P), 256, stream, P, FP(const int64_t, MPRG_F_PTAB0), FP(const int32_t, MPRG_F_DV),
-                    FP(const int64_t, MPRG_F_SUB), (int)F[MPRG_F_N_INIT], FP(int64_t, MPRG_F_VALS), FHDR);
-  return kf_count_done(F, P, 9, stream, "k_sz_count");
+                    FP(const int64_t, MPRG_F_SUB), (int)F[MPRG_F_N_INIT], FP(int64_t, MPRG_F_VALS), st.hdr, dn);
+  return kf_count_done(F, st, P, 9, dn, stream, "k_sz_count");
 }
-int mprg_forest_sizes_fill(const int64_t *F, void *stream) {
+static int kf_sizes_fill(const int64_t *F, const KfStep &st, const int64_t *n_p, void *stream) {
   const long long P = F[MPRG_F_P];
   if (P <= 0) return 0;
   LAUNCH(k_sz_fill, KF_GRID(P), 256, stream, P, FP(const int64_t, MPRG_F_PTAB0), FP(const int32_t, MPRG_F_DV), FP(const int64_t, MPRG_F_SUB),
-         FP(const int64_t, MPRG_F_VALS), FHDR, FP(int64_t, MPRG_F_PTAB), FP(int32_t, MPRG_F_CLS_LISTS), FP(int32_t, MPRG_F_NUM_CLUSTERS),
-         FP(int32_t, MPRG_F_ACTIVE), FP(int32_t, MPRG_F_WORK_COLS), FP(int32_t, MPRG_F_WORK_ROWS));
+         FP(const int64_t, MPRG_F_VALS), st.hdr, FP(int64_t, MPRG_F_PTAB), FP(int32_t, MPRG_F_CLS_LISTS), FP(int32_t, MPRG_F_NUM_CLUSTERS),
+         FP(int32_t, MPRG_F_ACTIVE), FP(int32_t, MPRG_F_WORK_COLS), FP(int32_t, MPRG_F_WORK_ROWS), kf_dc(st, kf_slot(st, n_p)));
   return check_launch("k_sz_fill");
 }
+static int kf_splits_count(const int64_t *F, const KfStep &st, const int64_t *n_p, void *stream) {
+  const long long P = F[MPRG_F_P];
+  const DsCount dn = kf_dc(st, kf_slot(st, n_p));
+  if (P > 0) LAUNCH(k_sp_count, KF_GRID(P), 256, stream, P, FP(const int64_t, MPRG_F_PTAB), FP(const int32_t, MPRG_F_NUM_CLUSTERS),
+                    FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_SUMMARY), FP(int64_t, MPRG_F_VALS), dn);
+  return kf_count_done(F, st, P, 3, dn, stream, "k_sp_count");
+}
+static int kf_splits_fill(const int64_t *F, const KfStep &st, const int64_t *n_p, void *stream) {
+  const long long P = F[MPRG_F_P];
+  if (P <= 0 || F[MPRG_F_NSPLITS] <= 0) return 0;
+  LAUNCH(k_sp_fill, KF_GRID(P), 256, stream, P, FP(const int64_t, MPRG_F_PTAB), FP(const int32_t, MPRG_F_NUM_CLUSTERS),
+         FP(const int64_t, MPRG_F_SELNODE), FP(const int64_t, MPRG_F_VALS), (long long)F[MPRG_F_POOL_USED], FP(int64_t, MPRG_F_SPT),
+         FP(int64_t, MPRG_F_SP), FP(int64_t, MPRG_F_SPLITNODE), kf_dc(st, kf_slot(st, n_p)));
+  return check_launch("k_sp_fill");
+}
+static int kf_split_children(const int64_t *F, const KfStep &st, const int64_t *n_splits, void *stream) {
+  const long long ns = F[MPRG_F_NSPLITS];
+  if (ns <= 0) return 0;
+  LAUNCH(k_sp_children, (ns + 3) / 4, 256, stream, FP(int64_t, MPRG_F_NODES), ns, (long long)F[MPRG_F_N_NODES], FP(const int64_t, MPRG_F_SP),
+         FP(const int64_t, MPRG_F_SPLITNODE), FP(const int32_t, MPRG_F_CHILD_SIZES), FP(const int64_t, MPRG_F_SPT),
+         FP(const int64_t, MPRG_F_SUMMARY), kf_dc(st, kf_slot(st, n_splits)));
+  return check_launch("k_sp_children");
+}
+#define KF_HOST KfStep{nullptr, FHDR}
+int mprg_forest_frontier_count(const int64_t *F, void *stream) { return kf_frontier_count(F, KF_HOST, stream); }
+int mprg_forest_frontier_fill(const int64_t *F, void *stream) { return kf_frontier_fill(F, KF_HOST, stream); }
+int mprg_forest_classify(const int64_t *F, void *stream) { return kf_classify(F, KF_HOST, nullptr, stream); }
+int mprg_forest_children(const int64_t *F, void *stream) { return kf_children(F, KF_HOST, stream); }
+int mprg_forest_cluster_count(const int64_t *F, void *stream) { return kf_cluster_count(F, KF_HOST, nullptr, stream); }
+int mprg_forest_cluster_fill(const int64_t *F, void *stream) { return kf_cluster_fill(F, KF_HOST, nullptr, stream); }
+int mprg_forest_problems_count(const int64_t *F, void *stream) { return kf_problems_count(F, KF_HOST, nullptr, stream); }
+int mprg_forest_problems_fill(const int64_t *F, void *stream) { return kf_problems_fill(F, KF_HOST, nullptr, stream); }
+int mprg_forest_sizes_count(const int64_t *F, void *stream) { return kf_sizes_count(F, KF_HOST, nullptr, stream); }
+int mprg_forest_sizes_fill(const int64_t *F, void *stream) { return kf_sizes_fill(F, KF_HOST, nullptr, stream); }
 int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream) {
   const long long P = F[MPRG_F_P];
   if (P <= 0) return 0;
@@ -431,28 +541,157 @@ int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream) {
          FP(const int32_t, MPRG_F_FURTHER), (int)F[MPRG_F_UOFF + (k <= KM_KMAX ? k : 0)], FP(int32_t, MPRG_F_FIT_LISTS), FHDR);
   return kf_publish(F, stream, "k_kl_advance");
 }
-int mprg_forest_splits_count(const int64_t *F, void *stream) {
-  const long long P = F[MPRG_F_P];
-  if (P > 0) LAUNCH(k_sp_count, KF_GRID(P), 256, stream, P, FP(const int64_t, MPRG_F_PTAB), FP(const int32_t, MPRG_F_NUM_CLUSTERS),
-                    FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_SUMMARY), FP(int64_t, MPRG_F_VALS));
-  return kf_count_done(F, P, 3, stream, "k_sp_count");
+int mprg_forest_splits_count(const int64_t *F, void *stream) { return kf_splits_count(F, KF_HOST, nullptr, stream); }
+int mprg_forest_splits_fill(const int64_t *F, void *stream) { return kf_splits_fill(F, KF_HOST, nullptr, stream); }
+int mprg_forest_split_children(const int64_t *F, void *stream) { return kf_split_children(F, KF_HOST, nullptr, stream); }
+
+int mprg_forest_state_init(int64_t *ds, long long n_words, long long n_roots, void *stream) {
+  if (n_words < MPRG_DS_GLOBAL) return fail("mprg_forest_state_init: the device state is at least MPRG_DS_GLOBAL words");
+  if (hipMemsetAsync(ds, 0, sizeof(int64_t) * n_words, (hipStream_t)stream) != hipSuccess) return fail("memset");
+  LAUNCH(k_ds_init, 1, 64, stream, ds, n_roots);
+  return check_launch("k_ds_init");
 }
-int mprg_forest_splits_fill(const int64_t *F, void *stream) {
-  const long long P = F[MPRG_F_P];
-  if (P <= 0 || F[MPRG_F_NSPLITS] <= 0) return 0;
-  LAUNCH(k_sp_fill, KF_GRID(P), 256, stream, P, FP(const int64_t, MPRG_F_PTAB), FP(const int32_t, MPRG_F_NUM_CLUSTERS),
-         FP(const int64_t, MPRG_F_SELNODE), FP(const int64_t, MPRG_F_VALS), (long long)F[MPRG_F_POOL_USED], FP(int64_t, MPRG_F_SPT),
-         FP(int64_t, MPRG_F_SP), FP(int64_t, MPRG_F_SPLITNODE));
-  return check_launch("k_sp_fill");
+// One recursion level, every step enqueued, nothing read back (include/mprg.h: "a recursion level WITHOUT a host wait").
+int mprg_forest_level(const int64_t *F, void *stream) {
+  int64_t *ds = FP(int64_t, MPRG_F_DS);
+  if (!ds) return fail("mprg_forest_level: MPRG_F_DS is not set");
+  const long long L = F[MPRG_F_LEVEL_INDEX];
+  const int64_t *C = F + MPRG_F_CAP;
+  auto blk = [&](int s) { return ds + MPRG_DS_GLOBAL + (L * 6 + s) * MPRG_FOREST_HDR; };
+  auto slot = [&](const int64_t *w) { return DsCount{ds, (int)(w - ds)}; };
+  const long long BIG = 0x7fffffffffffffffLL;
+  // caps: up to 16 column capacities (BIG: not limited), then two optional sum checks
+  auto check = [&](int step, int m, std::initializer_list<long long> caps, int col_a = -1, int field_a = 0, long long cap_a = 0, int col_b = -1,
+                   int field_b = 0, long long cap_b = 0, const int64_t *base = nullptr) {
+    DsCaps dcaps;
+    int q = 0;
+    for (long long v : caps) dcaps.cap[q++] = v;
+    for (; q < 16; ++q) dcaps.cap[q] = BIG;
+    LAUNCH(k_ds_check, 1, 64, stream, ds, base ? base : (const int64_t *)blk(step), m, dcaps, 100 * (L + 1) + step, col_a, field_a, cap_a, col_b, field_b,
+           cap_b);
+  };
+  const uint8_t *arena = FP(const uint8_t, MPRG_F_ARENA);
+  const int32_t *pool = FP(const int32_t, MPRG_F_POOL);
+  const int Lm = (int)F[MPRG_F_MIN_MATCH];
+  // ---- S1 frontier -> views -> column masks, partition
+  const long long cap_n = F[MPRG_F_N], cap_na = F[MPRG_F_N_VIEWS];
+  LAUNCH(k_ds_begin, 1, 64, stream, ds, blk(MPRG_STEP_FRONTIER), cap_n, 100 * (L + 1) + 9);
+  if (cap_n <= 0) {                              // the plan ends here: a frontier that is not empty is an overflow (k_ds_begin)
+    LAUNCH(k_ds_advance, 1, 64, stream, ds, (const int64_t *)blk(MPRG_STEP_CLASSIFY), (const int64_t *)blk(MPRG_STEP_SPLITS));
+    return check_launch("k_ds_advance");
+  }
+  int64_t *b0 = blk(MPRG_STEP_FRONTIER);
+  const KfStep st0{ds, b0};
+  if (kf_frontier_count(F, st0, stream) != 0) return -1;
+  {
+    const int rpc = (int)F[MPRG_F_RPC_IDX];
+    long long item_caps[5] = {BIG, BIG, BIG, BIG, BIG};
+    item_caps[rpc] = C[MPRG_CAP_ITEMS];
+    check(MPRG_STEP_FRONTIER, 11, {cap_na, C[MPRG_CAP_TCOLS], BIG, C[MPRG_CAP_NFUSED], C[MPRG_CAP_NOTHER], item_caps[0], item_caps[1], item_caps[2],
+                                   item_caps[3], item_caps[4], C[MPRG_CAP_NGAP]});
+  }
+  if (cap_na > 0) {
+    if (kf_frontier_fill(F, st0, stream) != 0) return -1;
+    const int rpc = (int)F[MPRG_F_RPC_IDX];
+    if (C[MPRG_CAP_NOTHER] > 0 &&
+        d_column_masks(arena, FP(const int64_t, MPRG_F_VIEWS), pool, FP(const int32_t, MPRG_F_MASK_WORK), (int)C[MPRG_CAP_ITEMS], 1024 >> rpc,
+                       FP(uint32_t, MPRG_F_MASK), stream, slot(b0 + 5 + rpc)) != 0) return -1;
+    const bool lists = C[MPRG_CAP_NFUSED] > 0;
+    if (d_partition(arena, FP(const int64_t, MPRG_F_VIEWS), pool, (int)cap_na, FP(const uint32_t, MPRG_F_MASK), Lm, FP(const int32_t, MPRG_F_GAP_WORK),
+                    (int)C[MPRG_CAP_NGAP], FP(uint32_t, MPRG_F_MAXRUN), FP(int32_t, MPRG_F_STACK), FP(int32_t, MPRG_F_IVFLAG), FP(int32_t, MPRG_F_IV),
+                    FP(int32_t, MPRG_F_NIV), FP(int32_t, MPRG_F_STATUS), FP(int32_t, MPRG_F_VIEW_OUT), FP(int32_t, MPRG_F_IV_PACKED),
+                    FP(int32_t, MPRG_F_IVC), lists ? FP(const int32_t, MPRG_F_FUSED_LIST) : nullptr, lists ? (int)C[MPRG_CAP_NFUSED] : 0,
+                    lists ? FP(const int32_t, MPRG_F_OTHER_LIST) : nullptr, lists ? (int)C[MPRG_CAP_NOTHER] : 0, stream, slot(b0 + 0), slot(b0 + 10),
+                    slot(b0 + 3), lists ? slot(b0 + 4) : slot(b0 + 0)) != 0) return -1;
+  }
+  // ---- S2 classify, children of multi-interval nodes, the selected views
+  int64_t *b1 = blk(MPRG_STEP_CLASSIFY);
+  const KfStep st1{ds, b1};
+  const long long cap_sel = F[MPRG_F_NSEL];
+  if (kf_classify(F, st1, b0 + 0, stream) != 0) return -1;
+  check(MPRG_STEP_CLASSIFY, 6, {BIG, cap_sel, C[MPRG_CAP_SROWS], C[MPRG_CAP_UBYTES], C[MPRG_CAP_SCOLS], C[MPRG_CAP_NDD]}, 0, MPRG_DS_NNODES,
+        C[MPRG_CAP_NODES]);
+  if (kf_children(F, st1, stream) != 0) return -1;
+  LAUNCH(k_ds_add, 1, 64, stream, ds, (int)MPRG_DS_NNODES, (const int64_t *)b1);
+  int64_t *b5 = blk(MPRG_STEP_SPLITS);
+  if (cap_sel > 0) {
+    // ---- row groups of the selected views; S3 which candidates go on
+    if (d_ungap_dedupe(arena, FP(const int64_t, MPRG_F_SUB), pool, (int)cap_sel, Lm, FP(const int32_t, MPRG_F_DD_WORK), (int)C[MPRG_CAP_NDD],
+                       FP(uint8_t, MPRG_F_UCODES), FP(uint64_t, MPRG_F_HASHES), FP(int32_t, MPRG_F_ULEN), FP(int32_t, MPRG_F_REP_U),
+                       FP(int32_t, MPRG_F_REP_G), FP(int32_t, MPRG_F_D_OF_ROW), FP(int32_t, MPRG_F_S_OF_ROW), FP(int32_t, MPRG_F_REPS_POS),
+                       FP(int32_t, MPRG_F_REPS_LEN), FP(int32_t, MPRG_F_SEQROW), FP(int64_t, MPRG_F_OCC_OFF), FP(int64_t, MPRG_F_SUMMARY),
+                       FP(uint8_t, MPRG_F_GCODES), stream, slot(b1 + 1), slot(b1 + 5)) != 0) return -1;
+    int64_t *b2 = blk(MPRG_STEP_CLUSTER);
+    const KfStep st2{ds, b2};
+    const long long cap_pq = F[MPRG_F_NPQ];
+    if (kf_cluster_count(F, st2, b1 + 1, stream) != 0) return -1;
+    check(MPRG_STEP_CLUSTER, 3, {cap_pq, C[MPRG_CAP_WC], C[MPRG_CAP_WR]});
+    if (cap_pq > 0) {
+      if (kf_cluster_fill(F, st2, b1 + 1, stream) != 0) return -1;
+      // cluster_sequences.py:256: `while cluster_further(...)` is evaluated before any KMeans (k = 1, one cluster)
+      if (d_cluster_further(arena, FP(const int64_t, MPRG_F_SUB), pool, FP(const int64_t, MPRG_F_T1), (int)cap_pq, 1, FP(const int32_t, MPRG_F_D_OF_ROW),
+                            nullptr, nullptr, FP(const int32_t, MPRG_F_WORK_COLS), (int)C[MPRG_CAP_WC], FP(const int32_t, MPRG_F_WORK_ROWS),
+                            (int)C[MPRG_CAP_WR], FP(int32_t, MPRG_F_CF_SCRATCH), FP(int32_t, MPRG_F_FURTHER), nullptr, FP(const uint8_t, MPRG_F_GCODES),
+                            nullptr, stream, slot(b2 + 1), slot(b2 + 2)) != 0) return -1;
+      // ---- S4 the clustering problems, their k-mer dictionaries
+      int64_t *b3 = blk(MPRG_STEP_PROBLEMS);
+      const KfStep st3{ds, b3};
+      const long long cap_p = F[MPRG_F_P];
+      if (kf_problems_count(F, st3, b2 + 0, stream) != 0) return -1;
+      check(MPRG_STEP_PROBLEMS, 4, {cap_p, C[MPRG_CAP_TABLE], C[MPRG_CAP_FLAG], C[MPRG_CAP_LO]});
+      if (cap_p > 0) {
+        if (kf_problems_fill(F, st3, b2 + 0, stream) != 0) return -1;
+        const DsCount dp = slot(b3 + 0);
+        LAUNCH(k_kmer_dictionary, cap_p, KD_THREADS, stream, FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_PTAB0), Lm,
+               FP(const uint8_t, MPRG_F_UCODES), FP(const int32_t, MPRG_F_SEQROW), FP(const int64_t, MPRG_F_OCC_OFF), FP(uint8_t, MPRG_F_TABLE),
+               FP(uint8_t, MPRG_F_FLAG), FP(int32_t, MPRG_F_DV), dp);
+        // ---- S5 count matrices, workspaces, launch classes
+        int64_t *b4 = blk(MPRG_STEP_SIZES);
+        const KfStep st4{ds, b4};
+        if (kf_sizes_count(F, st4, b3 + 0, stream) != 0) return -1;
+        check(MPRG_STEP_SIZES, 7, {C[MPRG_CAP_XD], C[MPRG_CAP_WSD], C[MPRG_CAP_CLS], C[MPRG_CAP_CLS + 1], C[MPRG_CAP_CLS + 2], C[MPRG_CAP_CLS + 3],
+                                   C[MPRG_CAP_CLS + 4]});
+        check(MPRG_STEP_SIZES, 4, {C[MPRG_CAP_LDS], C[MPRG_CAP_LDS + 1], C[MPRG_CAP_LDS + 2], C[MPRG_CAP_LDS + 3]}, -1, 0, 0, -1, 0, 0, b4 + 16);
+        if (kf_sizes_fill(F, st4, b3 + 0, stream) != 0) return -1;
+        LAUNCH(k_kmer_counts, cap_p, 512, stream, FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_PTAB), Lm, FP(const uint8_t, MPRG_F_UCODES),
+               FP(const int32_t, MPRG_F_SEQROW), FP(const int64_t, MPRG_F_OCC_OFF), FP(const uint8_t, MPRG_F_TABLE), FP(double, MPRG_F_X), dp);
+        for (int c = 0; c < 5; ++c) {
+          const long long n_c = C[MPRG_CAP_CLS + c];
+          if (n_c <= 0) continue;
+          const int32_t *lst = FP(const int32_t, MPRG_F_CLS_LISTS) + c * cap_p;
+          const int rc = c < 4 ? d_kmeans_prepare(FP(const int64_t, MPRG_F_PTAB), (int)n_c, FP(const double, MPRG_F_X), FP(double, MPRG_F_WS), lst, (int)n_c,
+                                                  C[MPRG_CAP_LDS + c], nullptr, 0, stream, slot(b4 + 2 + c))
+                               : d_kmeans_prepare(FP(const int64_t, MPRG_F_PTAB), (int)n_c, FP(const double, MPRG_F_X), FP(double, MPRG_F_WS), nullptr, 0, 0,
+                                                  lst, (int)n_c, stream, slot(b4 + 2 + c));
+          if (rc != 0) return -1;
+        }
+        // ---- S6 the clustering loop of every problem (cluster_sequences.py:256-274), statistics into the sizes block
+        if (d_cluster_loop(FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_PTAB), (int)cap_p, (int)F[MPRG_F_N_INIT], FP(const double, MPRG_F_UNIFORMS),
+                           (const int32_t *)(uintptr_t)F[MPRG_F_UOFF_HOST], FP(const double, MPRG_F_X), FP(double, MPRG_F_WS),
+                           FP(const int32_t, MPRG_F_D_OF_ROW), FP(const uint8_t, MPRG_F_GCODES), FP(int32_t, MPRG_F_CF_SCRATCH), FP(int32_t, MPRG_F_LABELS),
+                           FP(int32_t, MPRG_F_ASSIGN), FP(double, MPRG_F_KM_INFO), FP(int32_t, MPRG_F_KM_STATUS), FP(int32_t, MPRG_F_NUM_CLUSTERS),
+                           FP(int32_t, MPRG_F_ACTIVE), b4, (int)F[MPRG_F_LOOP_FORMS], stream, dp) != 0) return -1;
+        // ---- S7 MultiClusterNodes and their children
+        const KfStep st5{ds, b5};
+        const long long cap_ns = F[MPRG_F_NSPLITS];
+        if (kf_splits_count(F, st5, b3 + 0, stream) != 0) return -1;
+        check(MPRG_STEP_SPLITS, 1, {cap_ns}, 1, MPRG_DS_POOL_USED, C[MPRG_CAP_POOL], 2, MPRG_DS_NNODES, C[MPRG_CAP_NODES]);
+        LAUNCH(k_ds_check, 1, 64, stream, ds, (const int64_t *)b5, 3, DsCaps{{BIG, BIG, C[MPRG_CAP_NCHILD], BIG, BIG, BIG, BIG, BIG, BIG, BIG, BIG, BIG, BIG, BIG, BIG, BIG}},
+               100 * (L + 1) + MPRG_STEP_SPLITS, -1, 0, 0LL, -1, 0, 0LL);
+        if (cap_ns > 0) {
+          if (kf_splits_fill(F, st5, b3 + 0, stream) != 0) return -1;
+          LAUNCH(k_split_children, cap_ns, 64, stream, FP(const int64_t, MPRG_F_SUB), pool, FP(const int64_t, MPRG_F_SPT), FP(const int64_t, MPRG_F_SP),
+                 FP(const int32_t, MPRG_F_D_OF_ROW), FP(const int32_t, MPRG_F_S_OF_ROW), FP(const int32_t, MPRG_F_ASSIGN), FP(int32_t, MPRG_F_POOL),
+                 FP(int32_t, MPRG_F_CHILD_SIZES), slot(b5 + 0));
+          if (kf_split_children(F, st5, b5 + 0, stream) != 0) return -1;
+        }
+      }
+    }
+  }
+  LAUNCH(k_ds_advance, 1, 64, stream, ds, (const int64_t *)b1, (const int64_t *)b5);
+  return check_launch("mprg_forest_level");
 }
-int mprg_forest_split_children(const int64_t *F, void *stream) {
-  const long long ns = F[MPRG_F_NSPLITS];
-  if (ns <= 0) return 0;
-  LAUNCH(k_sp_children, (ns + 3) / 4, 256, stream, FP(int64_t, MPRG_F_NODES), ns, (long long)F[MPRG_F_N_NODES], FP(const int64_t, MPRG_F_SP),
-         FP(const int64_t, MPRG_F_SPLITNODE), FP(const int32_t, MPRG_F_CHILD_SIZES), FP(const int64_t, MPRG_F_SPT),
-         FP(const int64_t, MPRG_F_SUMMARY));
-  return check_launch("k_sp_children");
-}
+
 int mprg_forest_assemble_special(const int64_t *F, void *stream) {
   const long long n = F[MPRG_F_N_NODES];
   if (hipMemsetAsync(FHDR, 0, sizeof(int64_t) * MPRG_FOREST_HDR, (hipStream_t)stream) != hipSuccess) return fail("memset");

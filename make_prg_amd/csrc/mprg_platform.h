@@ -100,6 +100,16 @@ template <> MPRG_DEV void group_fetch8<2>(const double *p, int g, double *out) {
   out[4] = quad_perm<0xf5>(l0); out[5] = quad_perm<0xf5>(l1); out[6] = quad_perm<0xf5>(l2); out[7] = quad_perm<0xf5>(l3);
 }
 
+// ---- device-side counts (mprg_forest_level: a recursion level enqueued without a host wait)
+// The host sizes such a launch from a CAPACITY; the exact count is a word of the forest's device state `ds` that an earlier kernel
+// of the same stream wrote.  Workgroups / items beyond it return at once, and so does every kernel once an earlier step's totals
+// exceeded their capacity (ds[0], sticky: the host then repeats the forest with exact sizes).  ds == nullptr: the host's count is exact.
+struct DsCount { const int64_t *ds; int slot; };
+#define DS_HOST DsCount{nullptr, 0}
+MPRG_DEV long long ds_n(const DsCount c, long long host_n) { return c.ds ? (c.ds[0] ? 0 : (long long)c.ds[c.slot]) : host_n; }
+// first statement of a kernel whose workgroup b handles items [b * per, (b + 1) * per)
+#define DS_GUARD(dc, per) do { if ((dc).ds && (long long)BLOCK_ID * (per) >= ds_n(dc, 0)) return; } while (0)
+
 // ---- cell codes and view accessors (layout: include/mprg.h)
 #define C_GAP 4
 #define C_N 11

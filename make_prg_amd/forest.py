@@ -41,6 +41,17 @@ _F_NAMES = ("NODES N_NODES META N_MSAS FAILED ERR_FIRST POOL POOL_USED ARENA MAX
             "N_LEVELS VALS_MSA VALS_NODE VALS_POS N_SITES JOBS OUT MSA_BASE UOFF").split()
 FI = {name: i for i, name in enumerate(_F_NAMES)}
 FI["HDR_HOST"], FI["FIT_LISTS"], FI["KM_MODE"], FI["INDEX_OUT"], FI["EX_RECORDS"], FI["EX_ROWS"] = 80, 81, 82, 83, 84, 85
+# mprg_forest_level (a level without a host wait): device state, buffers the per-step host passes to the data entry points, capacities
+for _i, _n in enumerate("DS LEVEL_INDEX MASK MAXRUN STACK IVFLAG IV NIV STATUS IVC UCODES GCODES HASHES ULEN REP_U REP_G D_OF_ROW S_OF_ROW REPS_POS "
+                        "REPS_LEN SEQROW OCC_OFF CF_SCRATCH TABLE FLAG X WS LABELS ASSIGN UNIFORMS UOFF_HOST LOOP_FORMS CAP".split()):
+    FI[_n] = 96 + _i
+(CAP_TCOLS, CAP_NFUSED, CAP_NOTHER, CAP_ITEMS, CAP_NGAP, CAP_NODES, CAP_SROWS, CAP_UBYTES, CAP_SCOLS, CAP_NDD, CAP_WC, CAP_WR, CAP_TABLE, CAP_FLAG,
+ CAP_LO, CAP_XD, CAP_WSD) = range(17)
+CAP_CLS, CAP_LDS, CAP_NCHILD, CAP_POOL = 17, 22, 26, 27
+DS_OVERFLOW, DS_F0, DS_N, DS_NNODES, DS_POOL_USED, DS_LEVEL, DS_NFAILED, DS_GLOBAL, DS_LEVEL_WORDS = 0, 1, 2, 3, 4, 5, 6, 16, 6 * 96
+# levels without host waits once the engine has a plan (the previous forest of the same resident batch): MPRG_SPECULATIVE=0 keeps the
+# per-step host
+SPECULATIVE = os.environ.get("MPRG_SPECULATIVE", "1") != "0"
 # launch lists of a KMeans round (hdr 86..92): wave form by LDS class, general workgroup form, small workgroup form
 KM_LISTS = (("mprg_kmeans_fit_wave", 0), ("mprg_kmeans_fit_wave", 1), ("mprg_kmeans_fit_wave", 2), ("mprg_kmeans_fit_wave", 3),
             ("mprg_kmeans_fit", None), ("mprg_kmeans_fit_small", 0), ("mprg_kmeans_fit_small", 1))
@@ -56,7 +67,7 @@ KM_SPLIT_BELOW = int(os.environ.get("MPRG_KM_SPLIT_BELOW", "0"))
 # level), "rounds" = one set of launches per round k (the shape of rounds 1-3)
 KLOOP_FUSED = os.environ.get("MPRG_KLOOP", "fused") != "rounds"
 LOOP_GENERAL, LOOP_SMALL = "mprg_cluster_loop[general]", "mprg_cluster_loop[small]"          # names the fused launches are timed under
-F_FIELDS = 96
+F_FIELDS = 192
 PREPARE_CLASSES = 4                      # LDS classes of mprg_kmeans_prepare (+ the global-memory form)
 
 
@@ -85,6 +96,15 @@ class ForestEngine(BatchEngine):
             return self._hdr_host[:n_hdr].copy()
         return None
 
+    def _plan_note(self, rec, step: int, h):
+        """The per-step host writes down every step's totals: the next forest of this batch is sized from them (run_forest)."""
+        if rec is None:
+            rec = {s_: np.zeros(HDR, np.int64) for s_ in range(6)}
+            rec["rpc_idx"] = 4
+            self._plan_rec.append(rec)
+        rec[step][:len(h)] = h
+        return rec
+
     def _scratch(self, n_items: int):
         """vals / scan scratch of a count step over n_items items."""
         be = self.be
@@ -112,45 +132,83 @@ class ForestEngine(BatchEngine):
     def run_forest(self, root_level=0, root_is_tree_root=True):
         """The whole recursion forest of the resident batch, level by level.  root_level / root_is_tree_root (one value or
         one per alignment): re-entry below an existing parent (LeafNode._update_leaf, recursion_tree.py:374-376) starts at
-        the parent's nesting level and does not force a MultiIntervalNode."""
-        be = self.be
+        the parent's nesting level and does not force a MultiIntervalNode.
+        Two ways through a level: the per-step host (`_forest_level`: every step's totals are read back to size the next buffers,
+        ~6 waits per level) and — when this engine has a PLAN, the totals of every step of an earlier forest of the same resident
+        batch — mprg_forest_level: buffers sized from the plan, exact counts on the device, no wait until the forest is enqueued
+        (`_forest_speculative`); a total beyond its capacity makes the device drop the rest and the host falls back to the first
+        way (and a fresh plan)."""
         M = len(self._msas)
-        meta = np.asarray(self.meta, dtype=np.int64).reshape(M, 6)
-        self.meta_arr = meta
         per = lambda v, dt: np.asarray(v, dt) if isinstance(v, (list, tuple, np.ndarray)) else np.full(M, v, dt)
         root_levels, forced = per(root_level, np.int64), per(root_is_tree_root, bool)
-        self.failed = np.zeros(M, bool)
+        key = (root_levels.tobytes(), forced.tobytes())
+        self._forest_begin(root_levels, forced, key)
+        plan = getattr(self, "_plan", None)
+        done = False
+        if SPECULATIVE and plan is not None and plan["key"] == key and self.be.profile is None and len(self.ok):
+            done = self._forest_speculative(plan)
+            if not done:          # a capacity was exceeded: start over, exact sizes
+                self.counters["plan_misses"] = self.counters.get("plan_misses", 0) + 1
+                self._plan = None
+                self._forest_begin(root_levels, forced, key)
+        if not done:
+            self._plan_rec = []
+            f0, n = 0, len(self.ok)
+            while n:
+                self.counters["levels"] += 1
+                f0, n = self._forest_level(f0, n)
+                self._alive = {k: v for k, v in self._alive.items() if k in ("NODES", "META", "FAILED", "ERR_FIRST", "POOL", "ARENA", "HDR", "HDR_HOST")}
+            self._plan = dict(key=key, levels=self._plan_rec, n_nodes=self.n_nodes, pool_used=self.pool_used) if KLOOP_FUSED else None
+        self._nodes_hint, self._pool_hint = self.n_nodes + (self.n_nodes >> 4), self.pool_used + (self.pool_used >> 4)
+        self._forest_end(check_failed=not done or self._spec_failed)
+
+    def _forest_begin(self, root_levels, forced, key):
+        """Node table with the roots, row pool, per-locus flags, state fields.  What depends only on the resident batch (roots,
+        meta, initial flags) is uploaded once per batch and copied device-to-device afterwards: no wait for the stream here."""
+        be = self.be
+        M = len(self._msas)
+        const = getattr(self, "_dev_const", None)
+        if const is None or const["key"] != key:
+            meta = np.asarray(self.meta, dtype=np.int64).reshape(M, 6)
+            failed = np.zeros(M, bool)
+            for i in self.bad:
+                failed[i] = True
+            ok = np.nonzero(~failed)[0]
+            roots = np.zeros((len(ok), NODE_FIELDS), np.int64)
+            roots[:, N_MSA], roots[:, N_PARENT], roots[:, N_LEVEL], roots[:, N_ROWS_OFF] = ok, -1, root_levels[ok], -1
+            roots[:, N_NROWS], roots[:, N_NCOLS], roots[:, N_FLAGS] = meta[ok, 4], meta[ok, 5], np.where(forced[ok], NF_FORCED, 0)
+            roots[:, N_FIRST_CHILD], roots[:, N_LVL], roots[:, N_REPS_OFF], roots[:, N_NSEQ] = -1, -1, -1, 1
+            roots[:, N_ACHARS], roots[:, N_AUX] = meta[ok, 5], -1
+            root_of = np.full(M, -1, np.int64)
+            root_of[ok] = np.arange(len(ok))
+            const = self._dev_const = dict(key=key, meta=meta, failed=failed, ok=ok, root_of=root_of, roots_bytes=roots.nbytes,
+                                           d_roots=be.upload(roots) if len(ok) else None, d_meta=be.upload(meta) if M else be.zeros(16),
+                                           d_failed=be.upload(failed.astype(np.int32)) if M else be.zeros(16))
+        self.meta_arr, self.ok, self.root_of = const["meta"], const["ok"], const["root_of"]
+        ok = self.ok
+        self.failed = const["failed"].copy()
         self.errors: Dict[int, Exception] = dict(self.bad)
-        for i in self.bad:
-            self.failed[i] = True
-        ok = np.nonzero(~self.failed)[0]
-        self.root_of = np.full(M, -1, np.int64)
-        self.root_of[ok] = np.arange(len(ok))
-        roots = np.zeros((len(ok), NODE_FIELDS), np.int64)
-        roots[:, N_MSA], roots[:, N_PARENT], roots[:, N_LEVEL], roots[:, N_ROWS_OFF] = ok, -1, root_levels[ok], -1
-        roots[:, N_NROWS], roots[:, N_NCOLS], roots[:, N_FLAGS] = meta[ok, 4], meta[ok, 5], np.where(forced[ok], NF_FORCED, 0)
-        roots[:, N_FIRST_CHILD], roots[:, N_LVL], roots[:, N_REPS_OFF], roots[:, N_NSEQ] = -1, -1, -1, 1
-        roots[:, N_ACHARS], roots[:, N_AUX] = meta[ok, 5], -1
         self.F = np.zeros(F_FIELDS, np.int64)
         self._alive: Dict[str, object] = {}
         # capacity: what the previous forest of this engine needed (a resident batch is rebuilt step after step), else a guess
         # of 64 nodes per alignment; growing means a device-to-device copy of the table
         self.n_nodes = len(ok)
-        self.cap_nodes = max(getattr(self, "_nodes_hint", 0), 64 * len(ok), 1024)
-        self.d_nodes = be.empty(8 * NODE_FIELDS * self.cap_nodes)
-        if len(ok):
-            self.d_nodes = be.grown(be.upload(roots), roots.nbytes, 8 * NODE_FIELDS * self.cap_nodes)
+        self.cap_nodes = max(getattr(self, "_nodes_hint", 0), 64 * len(ok), 1024) if getattr(self, "cap_floor", 0) == 0 else \
+            max(getattr(self, "_nodes_hint", 0), len(ok), self.cap_floor)
+        self.d_nodes = be.grown(const["d_roots"], const["roots_bytes"], 8 * NODE_FIELDS * self.cap_nodes) if len(ok) else \
+            be.empty(8 * NODE_FIELDS * self.cap_nodes)
         self.pool_cap, self.pool_used = 4 * getattr(self, "_pool_hint", 0), 0
         self.d_pool = be.empty(max(self.pool_cap, 16))
         self.d_hdr = be.zeros(8 * HDR)
         if not hasattr(self, "_hdr_buf"):
             self._hdr_buf, raw = be.host_visible(8 * HDR)
             self._hdr_host = raw.view(np.int64)
-        self.d_failed = be.upload(self.failed.astype(np.int32)) if M else be.zeros(16)
-        self.d_err = be.upload(np.full(max(M, 1), np.iinfo(np.uint64).max, np.uint64))
-        self.d_meta = be.upload(meta) if M else be.zeros(16)
+        self.d_failed = be.grown(const["d_failed"], 4 * max(M, 1), 4 * max(M, 4))
+        self.d_err = be.full(8 * max(M, 1), 255)
+        self.d_meta = const["d_meta"]
         self.levels: List[dict] = []
         self._tab = None
+        self._spec_failed = False
         d_uni, uoff = self._uniforms_all()
         self._set(NODES=self.d_nodes, N_NODES=self.n_nodes, META=self.d_meta, N_MSAS=M, FAILED=self.d_failed, ERR_FIRST=self.d_err,
                   POOL=self.d_pool, POOL_USED=0, ARENA=self.d_arena, MAX_NESTING=self.max_nesting, MIN_MATCH=self.L,
@@ -158,14 +216,12 @@ class ForestEngine(BatchEngine):
         for k_, o_ in uoff.items():
             self.F[FI["UOFF"] + k_] = o_
         self._d_uni, self._uoff = d_uni, uoff
-        f0, n = 0, len(ok)
-        while n:
-            self.counters["levels"] += 1
-            f0, n = self._forest_level(f0, n)
-            self._alive = {k: v for k, v in self._alive.items() if k in ("NODES", "META", "FAILED", "ERR_FIRST", "POOL", "ARENA", "HDR", "HDR_HOST")}
-        self._nodes_hint, self._pool_hint = self.n_nodes + (self.n_nodes >> 4), self.pool_used + (self.pool_used >> 4)
-        # per-locus policy: the locus is dropped, the batch goes on; the first failing view in frontier order names the error
-        if M and len(ok):
+
+    def _forest_end(self, check_failed: bool):
+        """Per-locus policy: the locus is dropped, the batch goes on; the first failing view in frontier order names the error."""
+        be = self.be
+        M = len(self._msas)
+        if M and len(self.ok) and check_failed:
             failed_dev = be.download(self.d_failed, np.int32, M) != 0
             new = np.nonzero(failed_dev & ~self.failed)[0]
             if len(new):
@@ -178,6 +234,125 @@ class ForestEngine(BatchEngine):
                     self.errors[mi] = (SequenceCurationError("All sequences in this slice contained N. Redo sequence curation.")
                                        if code == 2 else PartitioningError("Failed interval partitioning"))
 
+    # ------------------------------------------------------------------------------------------------ levels without host waits
+    def _forest_speculative(self, plan) -> bool:
+        """Every level of the forest enqueued from the plan's totals (mprg_forest_level), then ONE wait and one look at the device
+        state.  False: some total did not fit (or the forest has more levels than the plan): nothing of this attempt is kept."""
+        be = self.be
+        levels = plan["levels"]
+        nL = len(levels)
+        cap = lambda x: int(x)          # the plan is this batch's own: its totals are the capacities
+        n_words = DS_GLOBAL + (nL + 1) * DS_LEVEL_WORDS
+        d_ds = be.empty(8 * n_words)
+        be.call("mprg_forest_state_init", be.ptr(d_ds), n_words, len(self.ok), be.stream)
+        # node table and row pool for the whole forest (no growing on the way)
+        self.cap_nodes = max(self.cap_nodes, cap(plan["n_nodes"]))
+        if 8 * NODE_FIELDS * self.cap_nodes > len(self.d_nodes):
+            self.d_nodes = be.grown(self.d_nodes, 8 * NODE_FIELDS * self.n_nodes, 8 * NODE_FIELDS * self.cap_nodes)
+        pool_entries = max(cap(plan["pool_used"]), 4)
+        if 4 * pool_entries > self.pool_cap:
+            self.pool_cap = 4 * pool_entries
+            self.d_pool = be.empty(self.pool_cap)
+        uoffs = np.zeros(MAX_CLUSTERS + 1, np.int32)
+        for k_, o_ in self._uoff.items():
+            uoffs[k_] = o_
+        self._uoffs_host = uoffs
+        small = bool(KM_MODE & 2)
+        self._set(NODES=self.d_nodes, POOL=self.d_pool, DS=d_ds, UNIFORMS=self._d_uni, LOOP_FORMS=(1 | 8 | 2 | 4) if small else 1)
+        self.F[FI["UOFF_HOST"]] = uoffs.ctypes.data
+        C = FI["CAP"]
+        self.F[C + CAP_NODES], self.F[C + CAP_POOL] = self.cap_nodes, self.pool_cap // 4
+        reps = []
+        for li in range(nL + 1):
+            keep = self._level_speculative(li, levels[li] if li < nL else None, cap)
+            reps.append(keep)
+            self.counters["launches"] += 1
+        # ---- the one wait of the forest: what happened
+        ds = be.download(d_ds, np.int64, n_words)
+        self.counters["syncs"] = self.counters.get("syncs", 0) + 1
+        if ds[DS_OVERFLOW] or ds[DS_N]:
+            return False
+        rec = []
+        for li in range(nL):
+            blk = ds[DS_GLOBAL + li * DS_LEVEL_WORDS:DS_GLOBAL + (li + 1) * DS_LEVEL_WORDS].reshape(6, HDR)
+            rec.append({s_: blk[s_].copy() for s_ in range(6)})
+            rec[-1]["rpc_idx"] = levels[li]["rpc_idx"]
+            b0, b1, b2, b4 = blk[0], blk[1], blk[2], blk[4]
+            self.counters["levels"] += 1
+            self.counters["cells_all"] += float(b0[11])
+            self.counters["cells_clustered"] += float(b2[3])
+            self.counters["fits"] += int(b4[80])
+            self.counters["kmeans_bytes"] += float(b4[85:86].view(np.float64)[0]) + float(b4[93:94].view(np.float64)[0])
+            if b4[82]:
+                raise MprgError("KMeans empty-cluster relocation: the selection ran out of frames (more than 5^10 samples in a fit)")
+            if b4[14]:
+                raise MprgError("k-mer dictionary: no hash seed separated the k-mers of a clustering problem (k-mer size > 16)")
+            if b4[15]:
+                raise MprgError("a k-mer count matrix has more than 4 194 304 features: beyond the KMeans kernels' pairwise-sum stack")
+            self.levels.append(dict(f0=int(b0[13]), n=int(b0[14]), reps_pos=reps[li][0], reps_len=reps[li][1], reps_rows=int(b1[2])))
+        self.n_nodes, self.pool_used = int(ds[DS_NNODES]), int(ds[DS_POOL_USED])
+        self._spec_failed = bool(ds[DS_NFAILED])
+        self._set(N_NODES=self.n_nodes, POOL_USED=self.pool_used)
+        self._plan = dict(key=plan["key"], levels=rec, n_nodes=self.n_nodes, pool_used=self.pool_used)
+        return True
+
+    def _level_speculative(self, li: int, pl, cap):
+        """Buffers of one level from the plan's totals `pl` (None: the level after the plan's last, which must find an empty
+        frontier), then the whole level in one call.  Returns the level's (reps_pos, reps_len) buffers, which PRG assembly reads."""
+        be = self.be
+        F = self.F
+        C = FI["CAP"]
+        F[FI["LEVEL_INDEX"]] = li
+        if pl is None:
+            self._set(N=0, LVL=li)
+            be.call("mprg_forest_level", F.ctypes.data, be.stream)
+            return (None, None)
+        h0, h1, h2, h3, h4, h5 = (pl[s_] for s_ in range(6))
+        n = cap(h0[14])
+        na, tcols, n_fused, n_other, n_gap = (cap(h0[q]) for q in (0, 1, 3, 4, 10))
+        rpc_idx = pl["rpc_idx"]
+        n_items = cap(h0[5 + rpc_idx])
+        nsel, srows, ubytes, scols, n_dd = (cap(h1[q]) for q in (1, 2, 3, 4, 5))
+        n_pq, n_wc, n_wr = (cap(h2[q]) for q in (0, 1, 2))
+        P, table_bytes, flag_bytes, lo = (cap(h3[q]) for q in (0, 1, 2, 3))
+        xd, wsd = cap(h4[0]), cap(h4[1])
+        n_splits, n_child = cap(h5[0]), cap(h5[2])
+        self._scratch(max(n, nsel, n_pq, P, 1))
+        e, z = be.empty, be.zeros
+        bufs = dict(VIEWS=e(8 * VF * na), VIEW2NODE=e(8 * na), FUSED_LIST=e(4 * n_fused), OTHER_LIST=e(4 * n_other), MASK_WORK=e(12 * n_items),
+                    GAP_WORK=e(8 * n_gap), VIEW_OUT=e(32 * na), IV_PACKED=e(12 * tcols), MASK=z(4 * tcols), MAXRUN=z(4 * tcols), STACK=e(16 * tcols),
+                    IVFLAG=z(8 * tcols), IV=e(12 * tcols), NIV=e(4 * na), STATUS=e(4 * na), IVC=z(4),
+                    SUB=e(8 * VF * nsel), SELNODE=e(8 * nsel), DD_WORK=e(8 * n_dd))
+        caps = {CAP_TCOLS: tcols, CAP_NFUSED: n_fused, CAP_NOTHER: n_other, CAP_ITEMS: n_items, CAP_NGAP: n_gap, CAP_SROWS: srows, CAP_UBYTES: ubytes,
+                CAP_SCOLS: scols, CAP_NDD: n_dd, CAP_WC: n_wc, CAP_WR: n_wr, CAP_TABLE: table_bytes, CAP_FLAG: flag_bytes, CAP_LO: lo, CAP_XD: xd,
+                CAP_WSD: wsd, CAP_NCHILD: n_child}
+        for c_ in range(5):
+            caps[CAP_CLS + c_] = cap(h4[2 + c_])
+        for c_ in range(4):
+            caps[CAP_LDS + c_] = int(h4[16 + c_])
+        keep = (None, None)
+        if nsel:
+            R = max(srows, 1)
+            bufs.update(UCODES=e(ubytes), GCODES=e(ubytes), HASHES=e(16 * R), ULEN=e(4 * R), REP_U=e(4 * R), REP_G=e(4 * R), D_OF_ROW=e(4 * R),
+                        S_OF_ROW=e(4 * R), REPS_POS=e(4 * R), REPS_LEN=e(4 * R), SEQROW=e(4 * R), OCC_OFF=e(8 * (R + nsel)), SUMMARY=e(64 * nsel))
+            keep = (bufs["REPS_POS"], bufs["REPS_LEN"])
+        if n_pq:
+            bufs.update(T1=e(8 * PF * n_pq), WORK_COLS=e(8 * n_wc), WORK_ROWS=e(8 * n_wr), CF_SCRATCH=e(12 * scols + 64), FURTHER=e(4 * n_pq))
+        if P:
+            bufs.update(PTAB0=e(8 * PF * P), TABLE=e(table_bytes), FLAG=e(flag_bytes), DV=e(4 * P), PTAB=e(8 * PF * P),
+                        CLS_LISTS=e(4 * (PREPARE_CLASSES + 1) * P), NUM_CLUSTERS=e(4 * P), ACTIVE=e(4 * P), KM_INFO=e(64 * P), KM_STATUS=z(4 * P),
+                        X=z(8 * xd), WS=e(8 * wsd), LABELS=e(4 * lo), ASSIGN=z(4 * lo))
+        if n_splits:
+            bufs.update(SPT=e(8 * PF * n_splits), SP=e(24 * n_splits), SPLITNODE=e(8 * n_splits), CHILD_SIZES=e(4 * n_child))
+        for name in ("WORK_COLS", "WORK_ROWS") if not n_pq else ():
+            F[FI[name]] = 0
+        self._set(N=n, LVL=li, N_VIEWS=na, RPC_IDX=rpc_idx, NSEL=nsel, NPQ=n_pq, P=P, NSPLITS=n_splits, **bufs)
+        for q_, v_ in caps.items():
+            F[C + q_] = v_
+        be.call("mprg_forest_level", F.ctypes.data, be.stream)
+        self._alive = {k: v for k, v in self._alive.items() if k in ("NODES", "META", "FAILED", "ERR_FIRST", "POOL", "ARENA", "HDR", "HDR_HOST", "DS", "UNIFORMS")}
+        return keep
+
     # ------------------------------------------------------------------------------------------------ level
     def _forest_level(self, f0: int, n: int):
         be, L = self.be, self.L
@@ -186,12 +361,15 @@ class ForestEngine(BatchEngine):
         self._scratch(n)
         self._set(F0=f0, N=n, LVL=lvl)
         h = self._step("frontier_count", n_hdr=13)
+        rec = self._plan_note(None, 0, h)
+        rec[0][13], rec[0][14] = f0, n
         na, total_cols, total_rows, n_fused, n_other = (int(x) for x in h[:5])
         items, n_gap, cells, cells_other = h[5:10], int(h[10]), float(h[11]), float(h[12])
         self.counters["cells_all"] += cells
         # the row chunk of a mask item is chosen so that a launch has >= ~1000 workgroups when the level offers that much work
         # (measured on MI355X: a 600 MB view streams at 4.9 TB/s with ~1200 workgroups of 512 rows x 1024 columns)
         rpc_idx = next((i for i in range(4) if items[i] >= 1024), 4)
+        rec["rpc_idx"] = rpc_idx
         n_items = int(items[rpc_idx])
         d_views, d_v2n = be.empty(8 * VF * na), be.empty(8 * na)
         d_fl, d_ol, d_mw, d_gw = be.empty(4 * n_fused), be.empty(4 * n_other), be.empty(12 * n_items), be.empty(8 * n_gap)
@@ -214,6 +392,7 @@ class ForestEngine(BatchEngine):
         # ---- S2: leaf / multi-interval / clustering candidate; children of multi-interval nodes
         self._set(VIEW_OUT=d_vout, IV_PACKED=d_ivp)
         h = self._step("classify", n_hdr=7)
+        self._plan_note(rec, 1, h)
         n_child_iv, nsel, tot_rows, tot_u, tot_cols, n_dd = (int(x) for x in h[:6])
         cells_sel = float(h[6])
         self._grow_nodes(self.n_nodes + n_child_iv)
@@ -239,6 +418,7 @@ class ForestEngine(BatchEngine):
         self._scratch(nsel)
         self._set(SUMMARY=dd["summary"])
         h = self._step("cluster_count", n_hdr=5)
+        rec = self._plan_note(self._plan_rec[-1], 2, h)
         n_pq, n_wc, n_wr = (int(x) for x in h[:3])
         self.counters["cells_clustered"] += float(h[3])
         if n_pq == 0:
@@ -254,6 +434,7 @@ class ForestEngine(BatchEngine):
         # ---- S4: the clustering problems, their k-mer dictionaries
         self._scratch(n_pq)
         h = self._step("problems_count", n_hdr=4)
+        self._plan_note(rec, 3, h)
         P, table_bytes, flag_bytes, lo = (int(x) for x in h)
         if P == 0:
             return 0
@@ -265,6 +446,7 @@ class ForestEngine(BatchEngine):
         # ---- S5: count matrices, workspaces, launch classes, biggest fits first
         self._scratch(P)
         h = self._step("sizes_count", n_hdr=21)
+        self._plan_note(rec, 4, h)
         if h[14]:
             raise MprgError("k-mer dictionary: no hash seed separated the k-mers of a clustering problem (k-mer size > 16)")
         if h[15]:
@@ -327,6 +509,7 @@ class ForestEngine(BatchEngine):
         # ---- S7: MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
         self._scratch(P)
         h = self._step("splits_count", n_hdr=HDR)
+        self._plan_note(rec, 5, h[:3])
         n_splits, rows_sp, n_child = (int(x) for x in h[:3])
         fits, cf_cells = int(h[80]), float(h[84:85].view(np.float64)[0])
         kb = {"mprg_kmeans_fit_wave": float(h[81:82].view(np.float64)[0]), "mprg_kmeans_fit": float(h[85:86].view(np.float64)[0]),

@@ -51,6 +51,9 @@ class EmuBackend(_Base):
     def zeros(self, nbytes):
         return np.zeros(max(int(nbytes), 16), np.uint8)
 
+    def full(self, nbytes, byte):
+        return np.full(max(int(nbytes), 16), int(byte), np.uint8)
+
     def upload(self, arr):
         a = np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()
         return a if a.size else self.empty(16)

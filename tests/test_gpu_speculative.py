@@ -1,0 +1,56 @@
+"""Levels without host waits on the MI355X (mprg_forest_level): the second and third forest of a resident batch against the first
+(per-step host) and against the oracle; capacities that are too small fall back.  Same checks as tests/test_speculative_emulated.py,
+through the HIP library."""
+import pytest
+
+from make_prg_amd.forest import ForestEngine
+from make_prg_amd.msa import load_alignment_text
+from make_prg_amd.utils.synthetic import synth_config_fasta
+from tests.random_msas import random_cases
+from tests.test_speculative_emulated import dump, reset
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["runtime", "torch"])
+def hip(request):
+    from make_prg_amd.backend import HipBackend, HipRuntimeBackend
+    return HipBackend(0) if request.param == "torch" else HipRuntimeBackend(0)
+
+
+@pytest.fixture(scope="module")
+def texts(golden_integration):
+    t = [synth_config_fasta("B", s) for s in range(40)] + [synth_config_fasta("C", s) for s in range(60)] + random_cases(5, 100)
+    t += [l["fasta"] for c in golden_integration["cases"] if c["case"] in ("fails_2", "contains_n") and (c["N"], c["L"]) == (5, 7) for l in c["loci"]]
+    return t
+
+
+def test_forests_from_a_plan_equal_the_first_and_the_oracle(hip, texts):
+    import oracle.from_msa_oracle as orc
+    eng = ForestEngine(hip, 5, 7)
+    eng.load([load_alignment_text(t) for t in texts])
+    eng.run_forest()
+    first = dump(eng, len(texts))
+    for i in (0, 39, 40, 99, 150):
+        assert first[0][i] == orc.build_locus_from_text(texts[i], 5, 7)[0]
+    for _ in range(3):
+        reset(eng)
+        eng.run_forest()
+        assert eng.counters["syncs"] == 1 and eng.counters.get("plan_misses", 0) == 0
+        assert dump(eng, len(texts)) == first
+
+
+@pytest.mark.parametrize("step,col", [(0, 1), (1, 1), (1, 3), (3, 0), (4, 1), (5, 2)])
+def test_small_capacities_fall_back(hip, texts, step, col):
+    eng = ForestEngine(hip, 5, 7)
+    eng.load([load_alignment_text(t) for t in texts[:60]])
+    eng.run_forest()
+    first = dump(eng, 60)
+    lv = next(l for l in eng._plan["levels"] if l[step][col] > 0)
+    lv[step][col] -= 1
+    reset(eng)
+    eng.run_forest()
+    assert eng.counters.get("plan_misses", 0) == 1 and dump(eng, 60) == first
+    reset(eng)
+    eng.run_forest()
+    assert eng.counters.get("plan_misses", 0) == 0 and eng.counters["syncs"] == 1 and dump(eng, 60) == first
