@@ -12,7 +12,7 @@ from tests.test_speculative_emulated import dump, reset
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["runtime", "torch"])
+@pytest.fixture(scope="module", params=["torch", "runtime"])
 def hip(request):
     from make_prg_amd.backend import HipBackend, HipRuntimeBackend
     return HipBackend(0) if request.param == "torch" else HipRuntimeBackend(0)
