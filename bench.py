@@ -136,7 +136,6 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None, backend_k
     of the rank's alignments.  The reference's own parallelism is a process pool over MSAs (from_msa `-t`); here the
     processes feed one GPU so that the array-at-a-time host control of several sub-batches overlaps."""
     try:
-        from concurrent.futures import ThreadPoolExecutor
         import numpy as np
         from make_prg_amd.backend import make_backend
         from make_prg_amd.forest import ForestEngine
@@ -157,24 +156,41 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None, backend_k
                 e.load(msas[i::n_streams])
             b.synchronize()
         t_ing = time.perf_counter() - t_ing
-        pool = ThreadPoolExecutor(n_streams)
         last = [None] * n_streams
 
-        def one(i):
-            with bes[i].on_stream():
-                engs[i].run_forest()                          # recursion forest: kernels; the host only sizes buffers
-                # PRG text (ASCII) of every locus of the sub-batch: laid out and written on the device, copied to a pinned
-                # host buffer on the copy stream; collected one step later, so the copy overlaps the next step's kernels
-                return engs[i].assemble_prgs(as_bytes=True, lazy=True)
+        def collect_one(i, fin):
+            prgs = fin()
+            last[i] = prgs
+            return sum(p is not None for p in prgs), sum(len(p) for p in prgs if p is not None)
 
-        def collect(fins):
-            n_ok = chars = 0
-            for i, fin in enumerate(fins):
-                prgs = fin()
-                last[i] = prgs
-                n_ok += sum(p is not None for p in prgs)
-                chars += sum(len(p) for p in prgs if p is not None)
-            return n_ok, chars
+        def run_steps(n_steps):
+            """n_steps passes over every sub-batch, ONE host thread.  An engine's step: wait for its forest (enqueued earlier without a
+            wait: forest.forest_enqueue, levels sized from the previous pass's totals, counts on the device), lay the PRG text out and
+            start its copy to pinned memory, enqueue the NEXT forest, then collect the previous step's text.  The engines take turns, so
+            while the host waits for one, the others' forests are queued on their own streams and fill the device (the first pass of a
+            batch has no plan yet: the per-step host runs it inside forest_enqueue)."""
+            pending = [None] * n_streams
+            totals = [(0, 0)] * n_streams
+            if n_steps <= 0:
+                return 0, 0
+            for i in range(n_streams):
+                with bes[i].on_stream():
+                    engs[i].forest_enqueue()
+            for step in range(n_steps):
+                for i in range(n_streams):
+                    with bes[i].on_stream():
+                        engs[i].forest_finish()
+                        # PRG text (ASCII) of every locus of the sub-batch: laid out and written on the device, copied to a pinned
+                        # host buffer on the copy stream; collected one step later, so the copy overlaps the next step's kernels
+                        fin = engs[i].assemble_prgs(as_bytes=True, lazy=True)
+                        if step + 1 < n_steps:
+                            engs[i].forest_enqueue()
+                    if pending[i] is not None:
+                        collect_one(i, pending[i])
+                    pending[i] = fin
+            for i in range(n_streams):
+                totals[i] = collect_one(i, pending[i])
+            return sum(t[0] for t in totals), sum(t[1] for t in totals)
 
         def end_to_end():
             """FASTA text (bytes in memory) -> PRG, .bin and .gfa bytes in memory, nothing resident beforehand: the stages of the
@@ -246,21 +262,8 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None, backend_k
         while True:
             cmd, arg = conn.recv()
             if cmd == "steps":
-                n_ok = chars = 0
                 t0 = time.perf_counter()
-                pending = None
-                trace = os.environ.get("MPRG_BENCH_TRACE")
-                for _ in range(arg):
-                    ts = time.perf_counter()
-                    fins = list(pool.map(one, range(n_streams)))
-                    tm = time.perf_counter()
-                    if pending is not None:
-                        collect(pending)
-                    pending = fins
-                    if trace:
-                        sys.stderr.write(f"[trace] step: enqueue+waits {1e3 * (tm - ts):.1f} ms, collect {1e3 * (time.perf_counter() - tm):.1f} ms\n")
-                if pending is not None:
-                    n_ok, chars = collect(pending)            # every step's text is on the host when the worker answers
+                n_ok, chars = run_steps(arg)                  # every step's text is on the host when the worker answers
                 for b in bes:
                     b.synchronize()
                 conn.send(("done", (n_ok, chars, time.perf_counter() - t0)))
@@ -287,7 +290,6 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None, backend_k
             elif cmd == "e2e":
                 conn.send(("done", end_to_end()))
             else:
-                pool.shutdown(wait=True)
                 return
     except BaseException as err:        # the parent must hear about it: there is no silent fallback
         import traceback

@@ -23,9 +23,20 @@
   hipLaunchKernelGGL(name, dim3((unsigned)(nblocks)), dim3((unsigned)(nthreads)), (size_t)(lds_bytes), (hipStream_t)(stream), __VA_ARGS__)
 #define BLOCK_ID ((int)blockIdx.x)
 #define N_THREADS ((int)blockDim.x)
-#define PAR_FOR(i, n) for (long long i = threadIdx.x; i < (long long)(n); i += blockDim.x)
+// MPRG_TID: the thread's index as PAR_FOR / ONE_THREAD see it — a FRESH copy at every use (one v_mov the compiler cannot see
+// through).  Why: a kernel that loops over a big inlined body (k_kloop.inc: the rounds of a clustering problem around ~30 000
+// instructions) would otherwise compute everything the body derives from the thread index once, before the loop, and keep it —
+// spilled to scratch and reloaded — across the whole body (241 scratch reloads per fit against 53; the reloads go through the
+// vector L1's address unit, the block the KMeans kernels saturate).
+#if defined(__HIP_DEVICE_COMPILE__)
+MPRG_DEV int mprg_tid_fresh() { int t; asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"((int)threadIdx.x)); return t; }
+#define MPRG_TID mprg_tid_fresh()
+#else
+#define MPRG_TID ((int)threadIdx.x)
+#endif
+#define PAR_FOR(i, n) for (long long i = MPRG_TID; i < (long long)(n); i += blockDim.x)
 #define BARRIER() __syncthreads()
-#define ONE_THREAD if (threadIdx.x == 0)
+#define ONE_THREAD if (MPRG_TID == 0)
 #define SHARED(T, name, n) __shared__ T name[n]
 typedef hipStream_t mprg_stream_t;
 #define ATOMIC_OR(p, v) atomicOr(p, v)

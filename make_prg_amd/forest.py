@@ -138,29 +138,50 @@ class ForestEngine(BatchEngine):
         batch — mprg_forest_level: buffers sized from the plan, exact counts on the device, no wait until the forest is enqueued
         (`_forest_speculative`); a total beyond its capacity makes the device drop the rest and the host falls back to the first
         way (and a fresh plan)."""
+        self.forest_enqueue(root_level, root_is_tree_root)
+        self.forest_finish()
+
+    def forest_enqueue(self, root_level=0, root_is_tree_root=True):
+        """First half of run_forest.  With a plan: the whole forest is ENQUEUED and the call returns (no wait; several engines on
+        streams of their own can be fed by one host thread in turn); without: the per-step host runs the forest here.
+        forest_finish() completes either."""
         M = len(self._msas)
         per = lambda v, dt: np.asarray(v, dt) if isinstance(v, (list, tuple, np.ndarray)) else np.full(M, v, dt)
         root_levels, forced = per(root_level, np.int64), per(root_is_tree_root, bool)
         key = (root_levels.tobytes(), forced.tobytes())
         self._forest_begin(root_levels, forced, key)
+        self._roots_args = (root_levels, forced, key)
         plan = getattr(self, "_plan", None)
-        done = False
+        self._pending_plan = None
         if SPECULATIVE and plan is not None and plan["key"] == key and self.be.profile is None and len(self.ok):
-            done = self._forest_speculative(plan)
-            if not done:          # a capacity was exceeded: start over, exact sizes
+            self._pending_plan = self._forest_speculative_enqueue(plan)
+        else:
+            self._forest_exact()
+
+    def forest_finish(self):
+        """Second half of run_forest: waits for a forest that was enqueued from a plan and looks at the device state (a total that
+        did not fit: the forest is repeated by the per-step host)."""
+        done_by_plan = False
+        if self._pending_plan is not None:
+            done_by_plan = self._forest_speculative_finish(*self._pending_plan)
+            self._pending_plan = None
+            if not done_by_plan:          # a capacity was exceeded: start over, exact sizes
                 self.counters["plan_misses"] = self.counters.get("plan_misses", 0) + 1
                 self._plan = None
-                self._forest_begin(root_levels, forced, key)
-        if not done:
-            self._plan_rec = []
-            f0, n = 0, len(self.ok)
-            while n:
-                self.counters["levels"] += 1
-                f0, n = self._forest_level(f0, n)
-                self._alive = {k: v for k, v in self._alive.items() if k in ("NODES", "META", "FAILED", "ERR_FIRST", "POOL", "ARENA", "HDR", "HDR_HOST")}
-            self._plan = dict(key=key, levels=self._plan_rec, n_nodes=self.n_nodes, pool_used=self.pool_used) if KLOOP_FUSED else None
+                self._forest_begin(*self._roots_args)
+                self._forest_exact()
         self._nodes_hint, self._pool_hint = self.n_nodes + (self.n_nodes >> 4), self.pool_used + (self.pool_used >> 4)
-        self._forest_end(check_failed=not done or self._spec_failed)
+        self._forest_end(check_failed=not done_by_plan or self._spec_failed)
+
+    def _forest_exact(self):
+        """The per-step host: every step's totals read back; writes the plan the next forest of this batch is sized from."""
+        self._plan_rec = []
+        f0, n = 0, len(self.ok)
+        while n:
+            self.counters["levels"] += 1
+            f0, n = self._forest_level(f0, n)
+            self._alive = {k: v for k, v in self._alive.items() if k in ("NODES", "META", "FAILED", "ERR_FIRST", "POOL", "ARENA", "HDR", "HDR_HOST")}
+        self._plan = dict(key=self._roots_args[2], levels=self._plan_rec, n_nodes=self.n_nodes, pool_used=self.pool_used) if KLOOP_FUSED else None
 
     def _forest_begin(self, root_levels, forced, key):
         """Node table with the roots, row pool, per-locus flags, state fields.  What depends only on the resident batch (roots,
@@ -235,9 +256,8 @@ class ForestEngine(BatchEngine):
                                        if code == 2 else PartitioningError("Failed interval partitioning"))
 
     # ------------------------------------------------------------------------------------------------ levels without host waits
-    def _forest_speculative(self, plan) -> bool:
-        """Every level of the forest enqueued from the plan's totals (mprg_forest_level), then ONE wait and one look at the device
-        state.  False: some total did not fit (or the forest has more levels than the plan): nothing of this attempt is kept."""
+    def _forest_speculative_enqueue(self, plan):
+        """Every level of the forest enqueued from the plan's totals (mprg_forest_level); no wait."""
         be = self.be
         levels = plan["levels"]
         nL = len(levels)
@@ -267,7 +287,14 @@ class ForestEngine(BatchEngine):
             keep = self._level_speculative(li, levels[li] if li < nL else None, cap)
             reps.append(keep)
             self.counters["launches"] += 1
-        # ---- the one wait of the forest: what happened
+        return plan, d_ds, n_words, reps
+
+    def _forest_speculative_finish(self, plan, d_ds, n_words, reps) -> bool:
+        """The ONE wait of a forest enqueued from a plan, and one look at the device state.  False: some total did not fit (or the
+        forest has more levels than the plan): nothing of the attempt is kept."""
+        be = self.be
+        levels = plan["levels"]
+        nL = len(levels)
         ds = be.download(d_ds, np.int64, n_words)
         self.counters["syncs"] = self.counters.get("syncs", 0) + 1
         if ds[DS_OVERFLOW] or ds[DS_N]:
