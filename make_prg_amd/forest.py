@@ -65,7 +65,12 @@ KM_SIDE_STREAMS = os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0"
 KM_SPLIT_BELOW = int(os.environ.get("MPRG_KM_SPLIT_BELOW", "0"))
 # the clustering loop: "fused" = a problem's workgroup walks k = 2..10 itself (mprg_cluster_loop; one launch per workgroup form and
 # level), "rounds" = one set of launches per round k (the shape of rounds 1-3)
-KLOOP_FUSED = os.environ.get("MPRG_KLOOP", "fused") != "rounds"
+# "auto" (default): fused below KLOOP_ROUNDS_FROM alignments in the engine, rounds from there on.  Measured on MI355X (profiles/r04/
+# loop_forms.md): the fused loop wins where launches and waits decide (3 750 alignments per step, one worker: 68.2 k against 65.8 k
+# alignments/s; 940: 25.5 against 29.8 ms per pass) and lets a forest be enqueued without waits; with several worker processes sharing
+# a saturated device and >= 7 500 alignments each the per-round kernels carry ~4 % less scratch traffic (95.2 k against 91.6 k)
+KLOOP = os.environ.get("MPRG_KLOOP", "auto")
+KLOOP_ROUNDS_FROM = int(os.environ.get("MPRG_KLOOP_ROUNDS_FROM", "6000"))
 LOOP_GENERAL, LOOP_SMALL = "mprg_cluster_loop[general]", "mprg_cluster_loop[small]"          # names the fused launches are timed under
 F_FIELDS = 192
 PREPARE_CLASSES = 4                      # LDS classes of mprg_kmeans_prepare (+ the global-memory form)
@@ -73,6 +78,11 @@ PREPARE_CLASSES = 4                      # LDS classes of mprg_kmeans_prepare (+
 
 class ForestEngine(BatchEngine):
     """load() as BatchEngine; run_forest() builds every tree of the batch; assemble_prgs() emits the PRG strings."""
+
+    @property
+    def kloop_fused(self) -> bool:
+        """Which form the clustering loop takes for this engine's batch (KLOOP above)."""
+        return KLOOP == "fused" or (KLOOP != "rounds" and len(self._msas) < KLOOP_ROUNDS_FROM)
 
     # ------------------------------------------------------------------------------------------------ plumbing
     def _set(self, **kw):
@@ -181,7 +191,7 @@ class ForestEngine(BatchEngine):
             self.counters["levels"] += 1
             f0, n = self._forest_level(f0, n)
             self._alive = {k: v for k, v in self._alive.items() if k in ("NODES", "META", "FAILED", "ERR_FIRST", "POOL", "ARENA", "HDR", "HDR_HOST")}
-        self._plan = dict(key=self._roots_args[2], levels=self._plan_rec, n_nodes=self.n_nodes, pool_used=self.pool_used) if KLOOP_FUSED else None
+        self._plan = dict(key=self._roots_args[2], levels=self._plan_rec, n_nodes=self.n_nodes, pool_used=self.pool_used) if self.kloop_fused else None
 
     def _forest_begin(self, root_levels, forced, key):
         """Node table with the roots, row pool, per-locus flags, state fields.  What depends only on the resident batch (roots,
@@ -509,7 +519,7 @@ class ForestEngine(BatchEngine):
         #      host wait per round.  The general form and the small forms are independent launches: side by side on a side stream.
         #      MPRG_KLOOP=rounds keeps the per-round launches of rounds 1-3 (k_kl_advance + fit lists + mprg_cluster_further).
         km_events, cf_events = [], []
-        if KLOOP_FUSED:
+        if self.kloop_fused:
             uoffs = np.zeros(MAX_CLUSTERS + 1, np.int32)
             for k_, o_ in self._uoff.items():
                 uoffs[k_] = o_
@@ -542,7 +552,7 @@ class ForestEngine(BatchEngine):
         kb = {"mprg_kmeans_fit_wave": float(h[81:82].view(np.float64)[0]), "mprg_kmeans_fit": float(h[85:86].view(np.float64)[0]),
               "mprg_kmeans_fit_small": float(h[93:94].view(np.float64)[0])}
         km_bytes = sum(kb.values())
-        if KLOOP_FUSED:          # a fused launch's algorithmic bytes: its fits' 8 D V (iterations + n_init) + the cells its cluster_further visits
+        if self.kloop_fused:          # a fused launch's algorithmic bytes: its fits' 8 D V (iterations + n_init) + the cells its cluster_further visits
             kb = {LOOP_GENERAL: kb["mprg_kmeans_fit"], LOOP_SMALL: kb["mprg_kmeans_fit_small"]}
             kb[LOOP_SMALL if (KM_MODE & 2) else LOOP_GENERAL] += cf_cells
         if h[82]:

@@ -61,8 +61,10 @@ def sort_key(path: Path) -> str:
 class _Outputs:
     """The run's containers, streamed."""
 
-    def __init__(self, prefix: str, ot, threads: int):
+    def __init__(self, prefix: str, ot, threads: int, segment: bool = False):
         self.prefix, self.ot = prefix, ot
+        self.segment = segment          # a rank's part of a multi-rank run: containers stay zips, the caller merges them
+        self.fa_index = []              # (locus, bytes of its ">locus\nPRG\n" record) in file order
         self.fa_fd = None
         self.zips = {}
         self.threads = threads
@@ -110,7 +112,7 @@ class _Outputs:
             os.close(self.fa_fd)
         for z in self.zips.values():
             z.close()
-        if self.n == 1:          # a single locus is written bare, not zipped (utils/input_output_files.py:104-131)
+        if self.n == 1 and not self.segment:          # a single locus is written bare, not zipped (utils/input_output_files.py:104-131)
             import zipfile
             for kind in ("bin", "gfa"):
                 if kind in self.zips:
@@ -130,8 +132,10 @@ def _ingest(lib, paths: List[Path], threads: int):
     return h, info
 
 
-def run_pipeline(files: List[Path], options, backend) -> int:
-    """Builds every locus of `files` and writes the run's output files.  Returns the number of loci built.
+def run_pipeline(files: List[Path], options, backend, segment: bool = False):
+    """Builds every locus of `files` and writes the run's output files.  Returns the number of loci built — or, for a rank's
+    SEGMENT of a multi-rank run (segment=True: containers stay zips even for one locus), the segment's index (segment_index).
+    
     backend: a backend object, or a function that makes one — it is called AFTER the ingest thread has started, so that reading
     and parsing the first chunks overlaps bringing up the device (0.2 s with the library's own runtime plumbing, 1 s with torch)."""
     from .subcommands import from_msa as drv
@@ -146,7 +150,7 @@ def run_pipeline(files: List[Path], options, backend) -> int:
     threads = max(1, int(getattr(options, "threads", 1) or 1))
     files = sorted(files, key=sort_key)
     chunks = [files[lo:lo + CHUNK] for lo in range(0, len(files), CHUNK)]
-    out = _Outputs(options.output_prefix, ot, threads)
+    out = _Outputs(options.output_prefix, ot, threads, segment)
     fasta = options.alignment_format == "fasta"
     q_in: "queue.Queue" = queue.Queue(maxsize=2)
     q_out: "queue.Queue" = queue.Queue()
@@ -234,7 +238,16 @@ def run_pipeline(files: List[Path], options, backend) -> int:
     if callable(backend) and hasattr(be, "close") and os.environ.get("MPRG_FAST_EXIT", "1") == "0":
         be.close()          # a backend made here is released here (the command line leaves through os._exit instead: un-pinning GBs is slow)
     _trace(f"outputs closed {since_process_start():.2f} s after the process started") if TRACE else None
-    return out.n
+    return segment_index(out) if segment else out.n
+
+
+def segment_index(out: "_Outputs") -> dict:
+    """What rank 0 needs to merge a rank's output segment into the run's files without reading it: the loci in file order with
+    the length of each .prg.fa record, and per container the members' CRC-32, size and local-header offset."""
+    idx = dict(n=out.n, prefix=out.prefix, fa=[[nm, int(ln)] for nm, ln in out.fa_index], zips={})
+    for kind, z in out.zips.items():
+        idx["zips"][kind] = [[nb.decode("utf-8"), crc, size, off] for nb, crc, size, off in z.entries]
+    return idx
 
 
 def _build_chunk(lib, be, options, threads, ci, chunk, h, info):
@@ -404,6 +417,7 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
         addr[:, 1], ln[:, 1] = t_addr[built], t_len[built]
         addr[:, 2], ln[:, 2] = blob.ctypes.data + blob.size - 1, 1
         keep.append(blob)
+        out.fa_index.extend(zip((names[i] for i in built.tolist()), ln.sum(axis=1).tolist()))
         jobs.append(timed("prg.fa", out.plan_fa(addr.reshape(-1), ln.reshape(-1), lib, WRITE_THREADS)))
     # ---- zip members of the arena path's loci
     okj = np.nonzero(ok)[0]

@@ -1,10 +1,11 @@
 """`from_msa` sub-command: same flags and output files as make_prg/subcommands/from_msa.py:18-198.
 
 Instead of one worker process per alignment, the input list is sharded over the ranks of the job (one process per
-GPU; a single process when run plainly) and each rank builds its shard as ONE level-synchronous batch on its device
-(make_prg_amd/engine.py).  Per-locus policy is the reference's: a SequenceCurationError skips the locus with a
-warning, an empty alignment aborts the run (EmptyMSAError).  Rank 0 gathers the per-locus outputs and writes
-<prefix>.prg.fa (loci in sorted order), <prefix>.prg.bin(.zip), <prefix>.prg.gfa(.zip), <prefix>.update_DS.zip.
+GPU; a single process when run plainly) and each rank streams its shard through the file -> file pipeline on its device
+(make_prg_amd/pipeline.py).  Per-locus policy is the reference's: a SequenceCurationError skips the locus with a
+warning, an empty alignment aborts the run (EmptyMSAError).  Under several ranks every rank writes segment files, rank 0 gathers
+the segments' INDEX (the job's one collective) and merges their byte ranges into <prefix>.prg.fa (loci in sorted order),
+<prefix>.prg.bin(.zip), <prefix>.prg.gfa(.zip), <prefix>.update_DS.zip (utils/segments.py).
 """
 import logging
 import os
@@ -70,7 +71,11 @@ def _dist():
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(backend)
+        _dist.we_initialised = True
     return dist.get_rank(), dist.get_world_size(), dist
+
+
+_dist.we_initialised = False
 
 
 def balanced_parts(files: List[Path], n_parts: int) -> List[List[Path]]:
@@ -259,65 +264,19 @@ def write_final_files(all_loci: Dict[str, dict], output_type, output_prefix: str
             _write_one(all_loci, k, output_prefix)
 
 
-# ---- the job's single exchange: every rank's per-locus output bytes to rank 0
-_FIELDS = ("prg", "pickle", "bin", "gfa")
-
-
-def pack_records(local: Dict[str, dict]) -> bytes:
-    """{locus: {prg (str), pickle / bin / gfa (bytes)}} -> one byte string: a JSON index (names, field lengths) then the
-    fields back to back.  No pickling of the dictionary: the payload of a 30 000-locus run is ~13 GB of bytes that are
-    only ever copied."""
-    import json
-    import struct
-    index, chunks = [], []
-    for locus in sorted(local):
-        rec = local[locus]
-        lens = []
-        for f in _FIELDS:
-            v = rec.get(f)
-            if v is None:
-                lens.append(-1)
-                continue
-            b = v.encode() if isinstance(v, str) else bytes(v)
-            lens.append(len(b))
-            chunks.append(b)
-        index.append([locus, lens])
-    head = json.dumps(index, separators=(",", ":")).encode()
-    return struct.pack("<Q", len(head)) + head + b"".join(chunks)
-
-
-def unpack_records(buf) -> Dict[str, dict]:
-    import json
-    import struct
-    mv = memoryview(buf)
-    (n,) = struct.unpack("<Q", mv[:8])
-    index = json.loads(bytes(mv[8:8 + n]))
-    pos = 8 + n
-    out: Dict[str, dict] = {}
-    for locus, lens in index:
-        rec = {}
-        for f, ln in zip(_FIELDS, lens):
-            if ln < 0:
-                continue
-            piece = bytes(mv[pos:pos + ln])
-            rec[f] = piece.decode() if f == "prg" else piece
-            pos += ln
-        out[locus] = rec
-    return out
-
-
+# ---- the job's single exchange: every rank's segment INDEX to rank 0
 GATHER_ROUND_BYTES = int(os.environ.get("MPRG_GATHER_ROUND_BYTES", str(1 << 30)))
 
 
-def gather_records(local: Dict[str, dict], dist, rank: int, world: int):
-    """all_gather of the ranks' byte counts, then the packed records gathered on rank 0 as uint8 in ROUNDS of at most
-    GATHER_ROUND_BYTES per rank (RCCL moves device tensors; gloo host tensors): rank 0 holds world x one round on the device,
-    never world x the largest payload, and no single collective comes near 2^31 bytes.  Returns the merged dictionary on rank 0,
-    None elsewhere."""
+def gather_bytes(payload: bytes, dist, rank: int, world: int):
+    """all_gather of the ranks' byte counts, then the payloads gathered on rank 0 as uint8 (RCCL moves device tensors, gloo host
+    tensors), in rounds of at most GATHER_ROUND_BYTES per rank.  Returns the list of the ranks' payloads on rank 0, None elsewhere.
+    What travels is each rank's segment index (loci, record lengths, members' CRC / size / offset: ~100 bytes per locus) — the
+    outputs themselves stay in the files the ranks wrote (utils/segments.py)."""
     import torch
     on_device = dist.get_backend() == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
-    payload = np.frombuffer(pack_records(local), dtype=np.uint8)
+    payload = np.frombuffer(payload, dtype=np.uint8)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([payload.size], dtype=torch.int64, device=dev))
     sizes = [int(t.item()) for t in sizes]
@@ -337,13 +296,27 @@ def gather_records(local: Dict[str, dict], dist, rank: int, world: int):
                 if take:
                     host[r][lo:lo + take] = t[:take].cpu().numpy()
         del parts, mine
-    if rank != 0:
-        return None
-    merged: Dict[str, dict] = {}
-    for r in range(world):
-        merged.update(unpack_records(host[r]))          # fields are copied out of a memoryview of the array, one by one
-        host[r] = None                                  # ... and the rank's payload is released before the next one
-    return merged
+    return [h.tobytes() for h in host] if rank == 0 else None
+
+
+def run_ranks(mine: List[Path], options, backend, dist, rank: int, world: int) -> int:
+    """A rank of a multi-GPU run: its size-balanced shard through the streamed one-GPU pipeline into SEGMENT files of its own; the
+    segment indexes gathered on rank 0 (the job's one collective); rank 0 merges the segments' byte ranges into the run's files
+    (utils/segments.py) — in the reference's order: every output lists the loci sorted (utils/input_output_files.py:89).
+    Returns the number of loci built (rank 0; 0 elsewhere)."""
+    import copy
+    from ..device import get_backend
+    from ..pipeline import run_pipeline, sort_key
+    from ..utils import segments
+    opts = copy.copy(options)
+    opts.output_prefix = f"{options.output_prefix}.rank{rank}"
+    idx = run_pipeline(mine, opts, backend or (lambda: get_backend("runtime")), segment=True)
+    got = gather_bytes(segments.pack_index(idx), dist, rank, world)
+    n = 0
+    if rank == 0:
+        n = segments.merge_segments([segments.unpack_index(b) for b in got], options.output_prefix,
+                                    sort_key=lambda locus: locus + ".prg.fa")
+    return n
 
 
 def run(cl_options, backend=None):
@@ -354,8 +327,10 @@ def run(cl_options, backend=None):
     # unusable); with an explicit backend (tests) everything runs in-process.
     n_workers = max(1, int(getattr(options, "threads", 1) or 1)) if backend is None else 1
     pool = None
-    single_rank_pipeline = int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("MPRG_PIPELINE", "1") != "0"
-    if n_workers > 1 and not single_rank_pipeline:
+    # the streamed pipeline (one GPU, or every rank of several) runs its host stages on `-t` THREADS of this process; only the
+    # object path (MPRG_PIPELINE=0, one rank) forks worker processes
+    pipeline = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("MPRG_PIPELINE", "1") != "0"
+    if n_workers > 1 and not pipeline:
         import multiprocessing as mp
         pool = mp.get_context("fork").Pool(n_workers)
     try:
@@ -387,6 +362,21 @@ def _run(options, backend, pool, n_workers):
         if n_built == 0:
             logger.error("No PRGs were built, please check errors")
         return
+    if dist is not None:
+        # several GPUs: every rank streams its shard into segment files, rank 0 merges them by an index (run_ranks)
+        import torch
+        n_built = run_ranks(mine, options, backend, dist, rank, world)
+        logger.info(f"rank {rank}: shard of {len(mine)} loci built and written in {time.time() - t0:.1f}s")
+        if dist.get_backend() == "nccl":
+            torch.cuda.synchronize()
+        dist.barrier()          # (the segments are merged and removed: every rank may leave)
+        if rank == 0:
+            logger.info(f"{n_built} loci in the merged output files after {time.time() - t0:.1f}s ({world} ranks)")
+            if n_built == 0:
+                logger.error("No PRGs were built, please check errors")
+        if _dist.we_initialised:
+            dist.destroy_process_group()
+        return
     if pool is not None and len(mine) >= 2 * n_workers:
         # several parts per worker, collected as they finish: the writer-side unpickling of one part overlaps the
         # building of the others (the per-locus outputs are ~0.5 MB each)
@@ -398,10 +388,6 @@ def _run(options, backend, pool, n_workers):
         local = build_shard(mine, options, backend)
     logger.info(f"rank {rank}: {len(local)} of {len(mine)} loci built in {time.time() - t0:.1f}s ({n_workers} host workers)")
     t0 = time.time()
-    if dist is not None:
-        local = gather_records(local, dist, rank, world)    # the single exchange of the job
-        if rank != 0:
-            return
     if not local:
         logger.error("No PRGs were built, please check errors")
         return

@@ -1,0 +1,150 @@
+"""Merging the ranks' output SEGMENTS of a multi-GPU from_msa run into the run's files (reference
+utils/input_output_files.py:73-162: per-locus temp files of every worker concatenated — sorted — and zipped at the end).
+
+Every rank streams its shard through the one-GPU pipeline (pipeline.py) into files of its own: `<prefix>.rank<r>.prg.fa`, the
+containers as STORED zips.  A stored member is a local header and the data, contiguous and position-independent; a `.prg.fa`
+record is two lines.  So the run's files are byte RANGES of the segments in the run's locus order plus one new central directory
+per container: rank 0 gets every rank's index (loci, record lengths, members' CRC / size / offset: a few MB through the job's one
+collective), copies the ranges inside the kernel (copy_file_range, falling back to read/write) and writes the directories.  The
+result equals what one rank writes for the whole input, byte for byte.  Nothing of the payload (22 GB for 30 000 loci with -O a)
+crosses RCCL or Python."""
+import json
+import os
+import struct
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, List
+
+import numpy as np
+
+from .zip_stream import StoredZipWriter
+
+COPY_THREADS = int(os.environ.get("MPRG_MERGE_THREADS", "4"))
+_KIND_FILE = {"bin": ".prg.bin.zip", "gfa": ".prg.gfa.zip", "pickle": ".update_DS.zip"}
+
+
+def pack_index(idx: dict) -> bytes:
+    return json.dumps(idx, separators=(",", ":")).encode()
+
+
+def unpack_index(blob) -> dict:
+    return json.loads(bytes(blob).decode())
+
+
+def _copy_range(src_fd: int, dst_fd: int, src_off: int, dst_off: int, n: int):
+    """n bytes from src_fd @ src_off to dst_fd @ dst_off, in the kernel where the file systems allow it."""
+    use_cfr = hasattr(os, "copy_file_range")
+    while n > 0:
+        if use_cfr:
+            try:
+                done = os.copy_file_range(src_fd, dst_fd, min(n, 1 << 30), src_off, dst_off)
+                if done > 0:
+                    n -= done; src_off += done; dst_off += done
+                    continue
+            except OSError:
+                pass
+            use_cfr = False          # (different file systems, an old kernel, a file system without it)
+        buf = os.pread(src_fd, min(n, 8 << 20), src_off)
+        if not buf:
+            raise OSError("a segment is shorter than its index says")
+        done = 0
+        while done < len(buf):
+            done += os.pwrite(dst_fd, memoryview(buf)[done:], dst_off + done)
+        n -= len(buf); src_off += len(buf); dst_off += len(buf)
+
+
+def _copy_plan(dst_path: str, seg_paths: List[str], seg: np.ndarray, src_off: np.ndarray, length: np.ndarray, dst_off: np.ndarray):
+    """Copies piece q = length[q] bytes of segment seg[q] @ src_off[q] to dst_off[q]; neighbouring pieces of one segment that are
+    neighbours in the destination too go as one range; a few threads share the ranges."""
+    n = len(seg)
+    if n == 0:
+        return
+    cont = (seg[1:] == seg[:-1]) & (src_off[1:] == src_off[:-1] + length[:-1]) & (dst_off[1:] == dst_off[:-1] + length[:-1])
+    first = np.concatenate([[True], ~cont])
+    run_id = np.cumsum(first) - 1
+    starts = np.nonzero(first)[0]
+    run_len = np.bincount(run_id, weights=length).astype(np.int64)
+    runs = list(zip(seg[starts].tolist(), src_off[starts].tolist(), dst_off[starts].tolist(), run_len.tolist()))
+    dst_fd = os.open(dst_path, os.O_WRONLY)
+    used = set(seg.tolist())          # (a rank without files wrote no segment)
+    fds = [os.open(p, os.O_RDONLY) if r in used else -1 for r, p in enumerate(seg_paths)]
+    try:
+        def work(part):
+            for s_, so, do, ln in part:
+                _copy_range(fds[s_], dst_fd, so, do, ln)
+        k = max(1, min(COPY_THREADS, len(runs)))
+        with ThreadPoolExecutor(k) as pool:
+            list(pool.map(work, [runs[q::k] for q in range(k)]))
+    finally:
+        os.close(dst_fd)
+        for fd in fds:
+            if fd >= 0:
+                os.close(fd)
+
+
+def merge_segments(indexes: List[dict], output_prefix: str, sort_key, keep_segments: bool = False) -> int:
+    """indexes[r]: rank r's segment_index (pipeline.py).  Writes <prefix>.prg.fa, .prg.bin(.zip), .prg.gfa(.zip), .update_DS.zip in
+    the run's locus order (sort_key(locus)) and removes the segments.  Returns the number of loci."""
+    # ---- the run's order
+    loci, rank_of, pos_in_rank = [], [], []
+    for r, idx in enumerate(indexes):
+        for q, (nm, _) in enumerate(idx["fa"] if idx["fa"] else []):
+            loci.append(nm); rank_of.append(r); pos_in_rank.append(q)
+    have_fa = any(idx["fa"] for idx in indexes)
+    kinds = sorted({k for idx in indexes for k in idx["zips"]})
+    if not have_fa:          # -O b / g only: the loci come from a container's members
+        for r, idx in enumerate(indexes):
+            for q, (nm, _, _, _) in enumerate(idx["zips"][kinds[0]] if kinds and kinds[0] in idx["zips"] else []):
+                loci.append(nm.rsplit(".", 1)[0] if kinds[0] != "pickle" else nm); rank_of.append(r); pos_in_rank.append(q)
+    n_loci = len(loci)
+    order = sorted(range(n_loci), key=lambda q: sort_key(loci[q]))
+    place = {loci[q]: p for p, q in enumerate(order)}          # locus -> its place in the run
+    seg_prefix = [idx["prefix"] for idx in indexes]
+    # ---- <prefix>.prg.fa
+    if have_fa:
+        src_off = [np.cumsum([0] + [ln for _, ln in idx["fa"]])[:-1] if idx["fa"] else np.zeros(0, np.int64) for idx in indexes]
+        seg = np.asarray([rank_of[q] for q in order], np.int64)
+        so = np.asarray([src_off[rank_of[q]][pos_in_rank[q]] for q in order], np.int64)
+        ln = np.asarray([indexes[rank_of[q]]["fa"][pos_in_rank[q]][1] for q in order], np.int64)
+        do = np.cumsum(ln) - ln
+        dst = output_prefix + ".prg.fa"
+        with open(dst, "wb") as fh:
+            fh.truncate(int(ln.sum()))
+        _copy_plan(dst, [p + ".prg.fa" for p in seg_prefix], seg, so, ln, do)
+    # ---- the containers: members in the run's order, one new central directory
+    for kind in kinds:
+        members = []          # (place, rank, name, crc, size, offset in the segment)
+        for r, idx in enumerate(indexes):
+            for nm, crc, size, off in idx["zips"].get(kind, []):
+                locus = nm if kind == "pickle" else nm[:-len(kind) - 1]
+                members.append((place.get(locus, n_loci), r, nm, crc, size, off))
+        members.sort(key=lambda m: (m[0], m[2]))
+        if not members:
+            continue
+        single = n_loci == 1 and kind != "pickle"          # a single locus is written bare (utils/input_output_files.py:104-131)
+        dst = f"{output_prefix}.prg.{kind}" if single else output_prefix + _KIND_FILE[kind]
+        head = np.asarray([30 + len(m[2].encode("utf-8")) for m in members], np.int64)
+        size = np.asarray([m[4] for m in members], np.int64)
+        seg = np.asarray([m[1] for m in members], np.int64)
+        so = np.asarray([m[5] for m in members], np.int64)
+        if single:
+            with open(dst, "wb") as fh:
+                fh.truncate(int(size[0]))
+            _copy_plan(dst, [p + _KIND_FILE[kind] for p in seg_prefix], seg, so + head, size, np.zeros(1, np.int64))
+            continue
+        ln = head + size
+        do = np.cumsum(ln) - ln
+        w = StoredZipWriter(dst, threads=1)
+        w._open()
+        os.ftruncate(w.fd, int(ln.sum()))
+        w.entries = [(m[2].encode("utf-8"), int(m[3]) & 0xFFFFFFFF, int(m[4]), int(o)) for m, o in zip(members, do.tolist())]
+        w.offset = int(ln.sum())
+        _copy_plan(dst, [p + _KIND_FILE[kind] for p in seg_prefix], seg, so, ln, do)
+        w.close()
+    if not keep_segments:
+        for p in seg_prefix:
+            for suffix in [".prg.fa"] + list(_KIND_FILE.values()):
+                try:
+                    os.remove(p + suffix)
+                except FileNotFoundError:
+                    pass
+    return n_loci

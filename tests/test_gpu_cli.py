@@ -76,3 +76,34 @@ def test_streamed_pipeline_equals_the_object_path_on_the_gpu(tmp_path):
     assert sorted(a["builders"]) == sorted(b["builders"]) and len(a["builders"]) == 17
     for l in a["builders"]:
         assert a["builders"][l].build_prg() == b["builders"][l].build_prg(), l
+
+
+def test_two_ranks_on_the_gpu_write_the_single_rank_files(tmp_path):
+    """`torchrun` with two ranks (gloo for the index exchange; both ranks on the one GPU of the box — RCCL refuses two ranks on one
+    device) against the plain command line: every rank streams its shard into segment files on the device, rank 0 merges them;
+    all four output files byte-identical, a gzipped file and a locus the curation policy skips among the inputs."""
+    import gzip
+    d = tmp_path / "msas"
+    d.mkdir()
+    for seed in range(800, 840):
+        text = synth_config_fasta("B" if seed % 3 else "C", seed)
+        if seed % 7 == 1:
+            with gzip.open(d / f"gene{seed}.fa.gz", "wt") as fh:
+                fh.write(text)
+        else:
+            (d / f"gene{seed}.fa").write_text(text)
+    (d / "bad.fa").write_text(">a\nACGTNNNNNNNNACGT\n>b\nACGANNNNNNNNACGT\n>c\nACGANNNNNNNNACGA\n")
+    env = dict(os.environ, PYTHONPATH=ROOT, MPRG_CHUNK="8", MPRG_DIST_BACKEND="gloo")
+    one, two = tmp_path / "one" / "pan", tmp_path / "two" / "pan"
+    args = ["from_msa", "-i", str(d), "-t", "4", "-O", "a"]
+    res = subprocess.run([sys.executable, "-m", "make_prg_amd"] + args + ["-o", str(one)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29547", "-m", "make_prg_amd"] + args + ["-o", str(two)], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    names = sorted(p.name for p in (tmp_path / "one").iterdir())
+    assert names == ["pan.prg.bin.zip", "pan.prg.fa", "pan.prg.gfa.zip", "pan.update_DS.zip"] == sorted(p.name for p in (tmp_path / "two").iterdir())
+    for n in names:
+        assert (tmp_path / "one" / n).read_bytes() == (tmp_path / "two" / n).read_bytes(), n
+    assert (tmp_path / "one" / "pan.prg.fa").read_text().count(">") >= 39

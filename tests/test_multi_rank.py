@@ -1,5 +1,6 @@
-"""N > 1 path: two ranks (gloo, CPU, emulation backend) shard a directory of alignments, rank 0 gathers and writes;
-the result must equal the single-process run byte for byte (.prg.fa) and member for member (zips)."""
+"""N > 1 path: ranks (gloo, CPU, emulation backend) shard a directory of alignments, every rank streams its shard into segment
+files (the one-GPU pipeline), rank 0 gathers the segments' index and merges their byte ranges; every output file must equal the
+single-process run's byte for byte."""
 import os
 import subprocess
 import sys
@@ -26,11 +27,12 @@ def test_two_ranks_equal_one(tmp_path, golden_integration):
                            "--master-addr", "127.0.0.1", "--master-port", "29533",
                            os.path.join(ROOT, "tests", "dist_worker.py"), str(d), str(two)], env=env)
     assert (tmp_path / "one" / "out.prg.fa").read_bytes() == (tmp_path / "two" / "out.prg.fa").read_bytes()
-    for kind in ("bin", "gfa"):
-        with zipfile.ZipFile(f"{one}.prg.{kind}.zip") as a, zipfile.ZipFile(f"{two}.prg.{kind}.zip") as b:
-            assert sorted(a.namelist()) == sorted(b.namelist()) and len(a.namelist()) == 9
-            for n in a.namelist():
-                assert a.read(n) == b.read(n)
+    for kind in ("prg.bin", "prg.gfa", "update_DS"):
+        # the ranks' segments merged by rank 0 ARE the single-rank files: same member order, headers, CRCs, central directory
+        assert open(f"{one}.{kind}.zip", "rb").read() == open(f"{two}.{kind}.zip", "rb").read(), kind
+        with zipfile.ZipFile(f"{two}.{kind}.zip") as b:
+            assert b.testzip() is None and len(b.namelist()) == 9
+    assert sorted(p.name for p in (tmp_path / "two").iterdir()) == ["out.prg.bin.zip", "out.prg.fa", "out.prg.gfa.zip", "out.update_DS.zip"]
 
 
 def test_four_ranks_with_skewed_file_sizes(tmp_path, golden_integration):
@@ -58,19 +60,53 @@ def test_four_ranks_with_skewed_file_sizes(tmp_path, golden_integration):
                            os.path.join(ROOT, "tests", "dist_worker.py"), str(d), str(four)], env=env)
     assert (tmp_path / "one" / "out.prg.fa").read_bytes() == (tmp_path / "four" / "out.prg.fa").read_bytes()
     for kind in ("prg.bin", "prg.gfa", "update_DS"):
-        with zipfile.ZipFile(f"{one}.{kind}.zip") as a, zipfile.ZipFile(f"{four}.{kind}.zip") as b:
-            assert sorted(a.namelist()) == sorted(b.namelist()) and len(a.namelist()) == len(files)
-            if kind != "update_DS":
-                for n in a.namelist():
-                    assert a.read(n) == b.read(n)
+        assert open(f"{one}.{kind}.zip", "rb").read() == open(f"{four}.{kind}.zip", "rb").read(), kind
+        with zipfile.ZipFile(f"{four}.{kind}.zip") as b:
+            assert b.testzip() is None and len(b.namelist()) == len(files)
 
 
-def test_record_packing_round_trip():
-    from make_prg_amd.subcommands.from_msa import pack_records, unpack_records
-    local = {"b": dict(prg="AC 5 G 6 T 5 ", pickle=b"\x80\x04", bin=b"\x01\x00\x00\x00", gfa=b"H\tVN\n"),
-             "a": dict(prg="", bin=b""), "c": dict(prg="ACGT")}
-    assert unpack_records(pack_records(local)) == local
-    assert unpack_records(pack_records({})) == {}
+def test_more_ranks_than_alignments(tmp_path):
+    """Three ranks, two alignments: a rank without files writes no segment and still takes part in the exchange."""
+    d = tmp_path / "msas"
+    d.mkdir()
+    for s in range(2):
+        (d / f"s{s}.fa").write_text(synth_config_fasta("B", s))
+    env = dict(os.environ, MPRG_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    one, three = tmp_path / "one" / "out", tmp_path / "three" / "out"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(d), str(one)], env=env)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                           "--master-addr", "127.0.0.1", "--master-port", "29539",
+                           os.path.join(ROOT, "tests", "dist_worker.py"), str(d), str(three)], env=env)
+    for name in ("out.prg.fa", "out.prg.bin.zip", "out.prg.gfa.zip", "out.update_DS.zip"):
+        assert (tmp_path / "one" / name).read_bytes() == (tmp_path / "three" / name).read_bytes(), name
+    assert len(list((tmp_path / "three").iterdir())) == 4
+
+
+def test_segment_index_round_trip_and_merge(tmp_path):
+    """The job's one collective carries segment INDEXES (utils/segments.py); the merge writes byte ranges of the segments in the
+    run's order and one central directory per container — here on two hand-made segments, checked with zipfile."""
+    import zlib
+    from make_prg_amd.utils import segments
+    from make_prg_amd.utils.zip_stream import StoredZipWriter
+    idxs = []
+    data = {0: {"b": b"BBBB", "d": b"D" * 70000}, 1: {"a": b"A", "c": b"CC"}}
+    for r, members in data.items():
+        prefix = str(tmp_path / f"o.rank{r}")
+        fa = b"".join(b">" + k.encode() + b"\n" + v + b"\n" for k, v in members.items())
+        open(prefix + ".prg.fa", "wb").write(fa)
+        z = StoredZipWriter(prefix + ".prg.bin.zip")
+        z.add_many([k + ".bin" for k in members], [[v] for v in members.values()], [zlib.crc32(v) for v in members.values()],
+                   [len(v) for v in members.values()])
+        z.close()
+        idxs.append(dict(n=len(members), prefix=prefix, fa=[[k, len(k) + len(v) + 3] for k, v in members.items()],
+                         zips={"bin": [[nb.decode(), crc, size, off] for nb, crc, size, off in z.entries]}))
+        assert segments.unpack_index(segments.pack_index(idxs[-1])) == idxs[-1]
+    n = segments.merge_segments(idxs, str(tmp_path / "o"), sort_key=lambda l: l + ".prg.fa")
+    assert n == 4
+    assert (tmp_path / "o.prg.fa").read_bytes() == b">a\nA\n>b\nBBBB\n>c\nCC\n>d\n" + b"D" * 70000 + b"\n"
+    with zipfile.ZipFile(tmp_path / "o.prg.bin.zip") as z:
+        assert z.testzip() is None and z.namelist() == ["a.bin", "b.bin", "c.bin", "d.bin"] and z.read("d.bin") == b"D" * 70000
+    assert not (tmp_path / "o.rank0.prg.fa").exists() and not (tmp_path / "o.rank1.prg.bin.zip").exists()
 
 
 def test_shards_are_disjoint_and_complete(tmp_path):

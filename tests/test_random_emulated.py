@@ -105,6 +105,6 @@ def test_clustering_loop_forms_agree(monkeypatch, golden_integration):
     monkeypatch.setattr(pc, "ENGINE", "forest")
     pc.check_vs_oracle(glob, random_cases(41, 60), 5, 7)
     assert pc.check_integration(glob, golden_integration) >= 30
-    monkeypatch.setattr(F, "KLOOP_FUSED", False)
+    monkeypatch.setattr(F, "KLOOP", "rounds")
     pc.check_vs_oracle(EmuBackend(), random_cases(42, 40), 5, 7)
     assert pc.check_integration(EmuBackend(), golden_integration) >= 30

@@ -18,7 +18,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "make_prg_amd", "_lib", "libmprg_hip_timing.so")
 msas = make_batch(list(range(n)), 16)[1]
 be = HipBackend(0, lib_path=lib)
-print('loop:', 'fused' if F.KLOOP_FUSED else 'rounds')
+print('loop:', F.KLOOP)
 eng = F.ForestEngine(be, 5, 7)
 eng.load(msas)
 eng.run_forest()
