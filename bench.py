@@ -46,7 +46,8 @@ DIGESTS = os.path.join(ROOT, "tests", "golden", "config_c_digests.bin")
 KERNEL_OF = {"mprg_kmeans_restarts": "k_kmeans_restart", "mprg_kmeans_fit": "k_kmeans_restart_select (persistent form: k_kmeans_fit)",
              "mprg_kmeans_fit_small": "k_kmeans_restart_select_small", "mprg_kmeans_fit_split": "k_kmeans_restart_one + k_kmeans_select_list", "mprg_kmeans_fit_wave": "k_kmeans_fit_wave",
              "mprg_column_masks": "k_column_masks", "mprg_partition": "k_partition (+ k_partition_fused, k_gap_runs, k_pack_scan, k_pack_copy)",
-             "mprg_ungap_dedupe": "k_ungap_dedupe (+ k_ungap_hash)", "mprg_emit_alleles": "k_emit_alleles",
+             "mprg_ungap_dedupe": "k_ungap_dedupe (+ k_ungap_hash, k_ungap_hash_u)", "mprg_emit_alleles": "k_emit_alleles",
+             "mprg_cluster_loop[general]": "k_cluster_loop", "mprg_cluster_loop[small]": "k_cluster_loop_small",
              "mprg_cluster_further": "k_cluster_majority + k_cluster_hamming",
              "mprg_kmeans_prepare": "k_kmeans_prepare_lds (+ k_kmeans_prepare, k_kmeans_prepare_tables)"}
 
@@ -306,6 +307,7 @@ def main():
                          "sharded over the ranks unless --weak")
     ap.add_argument("--weak", action="store_true", help="every rank builds all --batch alignments (weak scaling)")
     ap.add_argument("--no-single-worker-leg", action="store_true")
+    ap.add_argument("--no-shard-projection", action="store_true", help="skip the runs at the shard sizes of 2 / 4 / 8 GPUs (N=1 only)")
     ap.add_argument("--no-cli-leg", action="store_true", help="skip the file -> file run of the command line (N=1 only)")
     ap.add_argument("--cli-threads", type=int, default=0, help="-t of the command-line leg (0 = the CPUs this process may use, at most 16)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
@@ -313,7 +315,8 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--workers", type=int, default=4, help="host worker processes per GPU (each owns a sub-batch); capped by the "
                                                            "CPUs this rank may use")
-    ap.add_argument("--streams", type=int, default=1, help="host threads / HIP streams per worker process")
+    ap.add_argument("--streams", type=int, default=0, help="engines (sub-batches on HIP streams of their own, fed by ONE host thread) per worker "
+                                                           "process; 0 = by the shard's size (see below)")
     ap.add_argument("--profile-timed", action="store_true",
                     help="HIP events around every entry point INSIDE the timed region too (diagnostic; adds event traffic)")
     ap.add_argument("--gen-procs", type=int, default=0, help="processes per worker that generate its alignments (0 = auto)")
@@ -335,7 +338,7 @@ def main():
     cpu = None
     # CPU baseline first, before this process or its workers touch the GPU (fork-safe, and nothing else is running)
     if world == 1 and not args.no_cpu_baseline:
-        n = args.cpu_sample or max(ncpu * 6, 48)
+        n = args.cpu_sample or max(ncpu * 6, 1000)          # ~9 s on 16 cores: beyond start-up noise (a fixed 1 000-alignment subsample)
         v_e2e, v_build, dt = cpu_baseline(n, ncpu)
         calib = ""
         try:
@@ -362,9 +365,16 @@ def main():
         except Exception:
             avail_kib = 64 << 20
         W = max(1, min(W, max(1, (ncpu - 1) // max(world, 1)), int(avail_kib / (4 << 20) / 4 / max(world, 1))))
-    # one host worker on the GPU: nothing else fills the device while a round's two or three launch lists (independent launches
-    # of different kernels) drain one after the other, so they go to side streams (forest.KM_SIDE_STREAMS; measured, one worker:
-    # +11 % at 3 750 alignments per step, +1 % at 30 000; with four workers sharing the GPU: -4 %, off)
+    # The shape of a rank's host side follows its shard (measured on MI355X, profiles/r04/host_shapes.md):
+    #   a small shard (what a rank of an 8-GPU run sees: 3 750 alignments per step) is built best by ONE worker process whose single
+    #   host thread feeds TWO engines (sub-batches on streams of their own; forests enqueued without waits from the previous pass's
+    #   totals, forest.forest_enqueue) with the clustering loop's general and small forms side by side on a side stream:
+    #   76.1 k alignments/s against 67.9 k with one engine and 75.2 k with four worker processes;
+    #   a big shard by several worker processes with one engine each (30 000: 95.3 k with four; two engines each: 90.5 k).
+    if args.workers == 4 and len(seeds) <= 5000 and W >= 1:          # (an explicit --workers other than the default is respected)
+        W = 1
+    if args.streams == 0:
+        args.streams = 2 if (W == 1 and len(seeds) <= 12000) else 1
     if W == 1:          # (not --workers 0: the rocprofv3 runs want one kernel at a time)
         os.environ.setdefault("MPRG_KM_SIDE_STREAMS", "1")
     gen_procs = args.gen_procs or max(1, min(16, ncpu // (max(W, 1) * max(world, 1))))
@@ -464,6 +474,18 @@ def main():
         bad = sorted(x for b in bad_lists for x in b)
         verified = dict(loci=len(seeds), mismatches=len(bad), first_bad=bad[:10],
                         against="tests/golden/config_c_digests.bin (oracle: sha256(PRG)[:8] + node count per seed)")
+        try:          # which reference the digests are tied to, and how much of this data the reference itself decides stably
+            tie = json.load(open(os.path.join(ROOT, "tests", "golden", "config_c_reference_tie.json")))
+            st = tie["stability"]
+            verified["reference_tie"] = dict(
+                parity="Haswell-pinned: the REAL reference (make_prg v0.5.0, scikit-learn n_init=10, OMP_NUM_THREADS=1, OPENBLAS_CORETYPE=Haswell) "
+                       f"gives these digests for seeds {tie['config_c']['seeds']} ({tie['config_c']['equal_to_digest_fixture']} equal, container run "
+                       "oracle/tools/tie_reference.py)",
+                stable_loci=st["stable"], unstable_loci=st["unstable"], of=st["stable"] + st["unstable"], families=st["families"],
+                note="stable = PRG byte-identical under all five OpenBLAS kernel families; on the rest the real reference's own answer "
+                     "depends on the CPU it runs on (exact k-means++ / centre ties decided by the last bits of BLAS sums) — parity is to the pinned run")
+        except Exception:
+            pass
     if world > 1:
         flag = torch.tensor([0 if verified is None else verified["mismatches"]], dtype=torch.float64,
                             device=device if (dist_backend == "nccl" and world > 1) else "cpu")
@@ -511,6 +533,32 @@ def main():
         except Exception as err:          # reported, not hidden
             single = dict(error=f"{type(err).__name__}: {err}"[:300])
 
+    # ---- what one GPU of an N-GPU strong-scaling run sees: the job's alignments / N per step, measured on this GPU with one and
+    #      with four host workers (fresh child processes).  The driver computes scaling from its own 8-GPU runs; this is the
+    #      projection a one-GPU box can make: N x shard rate / value.
+    projection = None
+    if rank == 0 and world == 1 and W >= 1 and not args.no_shard_projection and not args.no_single_worker_leg:
+        import subprocess
+        projection = dict(note="alignments per step = batch / N on ONE GPU (what a rank of an N-GPU run builds); projected speed-up = "
+                               "N x shard rate / value of this line", shards=[])
+        for n_gpus in (2, 4, 8):
+            shard = args.batch // n_gpus
+            entry = dict(n_gpus=n_gpus, alignments_per_step=shard)
+            for label, w in (("one_worker", "1"), ("default_workers", "4")):
+                cmd = [sys.executable, os.path.abspath(__file__), "--workers", w, "--steps", "6", "--warmup", "2", "--batch", str(shard),
+                       "--no-cpu-baseline", "--no-end-to-end", "--no-single-worker-leg", "--no-cli-leg", "--no-shard-projection"]
+                try:
+                    line = subprocess.run(cmd, capture_output=True, text=True, timeout=900, check=True).stdout.strip().splitlines()[-1]
+                    one = json.loads(line)
+                    c1 = one["config"]
+                    entry[label] = dict(value=one["value"], ms_per_step=one["ms_per_step"], worker_processes=c1["host_worker_processes_per_gpu"],
+                                        engines_per_worker=c1["streams_per_worker"], host_waits_per_step=c1["host_waits_per_step"],
+                                        calls_per_step=c1["launches_per_step"], verified_mismatches=c1["verified"]["mismatches"],
+                                        projected_speedup=round(n_gpus * one["value"] / value, 3))
+                except Exception as err:          # reported, not hidden
+                    entry[label] = dict(error=f"{type(err).__name__}: {err}"[:300])
+            projection["shards"].append(entry)
+
     # ---- the command line, file -> file: the same alignments as FASTA files on local disk -> .prg.fa, .prg.bin.zip, .prg.gfa.zip,
     #      update_DS.zip (-O a); a fresh process, so the rate includes interpreter + device start-up
     cli = None
@@ -549,8 +597,19 @@ def main():
                        region="python -m make_prg_amd from_msa: FASTA files on local disk -> every output file (a fresh process: "
                               "interpreter, torch import and device start-up included; pipeline_seconds = after the input list is read)",
                        output_bytes=sizes, prgs_checked_against_digests=checked, mismatches=int(bad_cli))
+            # the same command with -O p (.prg.fa + update_DS.zip): the build-bound rate of the command line — -O a is bound by
+            # writing the 9.6 GB .prg.bin.zip
+            shutil.rmtree(os.path.join(cli_root, "out"), ignore_errors=True)
+            cmd_p = [c_ if c_ != "a" else "p" for c_ in cmd]
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd_p, cwd=ROOT, capture_output=True, text=True, timeout=1800)
+            dt_p = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr[-400:])
+            cli["prg_only"] = dict(value=round(len(seeds) / dt_p, 3), unit="MSAs/s", seconds=round(dt_p, 3), output_types="p (.prg.fa, update_DS.zip)",
+                                   output_bytes={n_: os.path.getsize(os.path.join(cli_root, "out", n_)) for n_ in sorted(os.listdir(os.path.join(cli_root, "out")))})
         except Exception as err:          # reported, not hidden
-            cli = dict(error=f"{type(err).__name__}: {err}"[:400])
+            cli = dict(cli or {}, error=f"{type(err).__name__}: {err}"[:400])
         shutil.rmtree(cli_root, ignore_errors=True)
 
     # whole-job counters (strong scaling: a rank's workers only saw its shard)
@@ -581,14 +640,14 @@ def main():
         # exactly these kernel sources; otherwise null
         traffic = traffic_note = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03", "pmc_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r04", "pmc_summary.json")))
             if pm.get("source_digest") == source_digest():
                 # the PMC passes profile a different batch (8192 alignments in one process), so their bytes per launch are
                 # not this pass's: what carries over is HBM bytes / algorithmic bytes of the entry point, measured there
                 ratio = pm["entry_points"][name]["traffic_over_algorithmic"]
                 traffic = round(ratio * top["algorithmic_bytes_per_launch"], 1)
                 traffic_note = (f"{ratio} x algorithmic bytes: (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes of {name} in the PMC "
-                                f"passes of the same sources (profiles/r03/pmc_summary.json, source_digest {pm['source_digest']})")
+                                f"passes of the same sources (profiles/r04/pmc_summary.json, source_digest {pm['source_digest']})")
         except Exception:
             pass
         roof = dict(bound="hbm", kernel=top["kernel"], entry_point=name, achieved=top["achieved_GBps"] or 0.0,
@@ -611,7 +670,7 @@ def main():
                                    "SURVEY.md §8d generator, seeds 0..batch-1), -N 5 -L 7; one step = every alignment of the job, "
                                    "resident, sharded over the ranks by size (--weak: all of them on every rank)",
                        "alignments_per_step": msas_per_step, "alignments_rank0": len(seeds), "parallelism": f"shard{world}",
-                       "host_worker_processes_per_gpu": W, "cpus_rank0": ncpu, "km_side_streams": os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0", "single_worker": single, "cli": cli,
+                       "host_worker_processes_per_gpu": W, "cpus_rank0": ncpu, "shard_projection": projection, "km_side_streams": os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0", "single_worker": single, "cli": cli,
                        "streams_per_worker": args.streams, "event_timing_in_timed_region": bool(args.profile_timed),
                        "step_includes": "recursion forest (kernels + device-side bookkeeping; the host sizes buffers from one header per "
                                         "step) + PRG text laid out and written on the device + its copy to pinned host memory",

@@ -348,6 +348,7 @@ enum {
   MPRG_F_D_OF_ROW = 112, MPRG_F_S_OF_ROW = 113, MPRG_F_REPS_POS = 114, MPRG_F_REPS_LEN = 115, MPRG_F_SEQROW = 116, MPRG_F_OCC_OFF = 117,
   MPRG_F_CF_SCRATCH = 118, MPRG_F_TABLE = 119, MPRG_F_FLAG = 120, MPRG_F_X = 121, MPRG_F_WS = 122, MPRG_F_LABELS = 123, MPRG_F_ASSIGN = 124,
   MPRG_F_UNIFORMS = 125, MPRG_F_UOFF_HOST = 126 /* HOST int32 [11] */, MPRG_F_LOOP_FORMS = 127 /* MPRG_LOOP_* */,
+  MPRG_F_SIDE_STREAM = 160 /* optional: a second stream; the small forms of the clustering loop run there beside the general form */,
   MPRG_F_CAP = 128 /* + MPRG_CAP_* */,
   MPRG_F_FIELDS = 192
 };

@@ -218,13 +218,18 @@ class HipBackend(_Base):
 
     # buffers are flat uint8 tensors; sizes in bytes
     def empty(self, nbytes: int):
-        return self.torch.empty(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
+        with self.torch.cuda.stream(self.stream_obj):          # (the caching allocator hands a freed block to later allocations of the SAME stream)
+            return self.torch.empty(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
 
+    # (fills and copies are enqueued on the BACKEND's stream whatever torch's current stream is: a forest that is enqueued without
+    #  host waits has nothing else that would order them against the kernels)
     def zeros(self, nbytes: int):
-        return self.torch.zeros(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
+        with self.torch.cuda.stream(self.stream_obj):
+            return self.torch.zeros(max(int(nbytes), 16), dtype=self.torch.uint8, device=self.device)
 
     def full(self, nbytes: int, byte: int):
-        return self.torch.full((max(int(nbytes), 16),), int(byte), dtype=self.torch.uint8, device=self.device)
+        with self.torch.cuda.stream(self.stream_obj):
+            return self.torch.full((max(int(nbytes), 16),), int(byte), dtype=self.torch.uint8, device=self.device)
 
     def upload(self, arr: np.ndarray):
         arr = np.ascontiguousarray(arr)
@@ -237,7 +242,8 @@ class HipBackend(_Base):
         nbytes = int(count) * np.dtype(dtype).itemsize
         if nbytes == 0:
             return np.empty(0, dtype)
-        return buf[:nbytes].cpu().numpy().view(dtype)
+        with self.torch.cuda.stream(self.stream_obj):          # (behind everything enqueued on the backend's stream)
+            return buf[:nbytes].cpu().numpy().view(dtype)
 
     def pinned(self, nbytes: int, key):
         """(buffer, uint8 array over it): page-locked host memory for uploads, kept and reused per `key` (grown when needed:
@@ -253,7 +259,8 @@ class HipBackend(_Base):
         """Device copy of the first nbytes of a pinned() buffer, enqueued on the compute stream (no staging copy)."""
         if nbytes == 0:
             return self.empty(16)
-        return pinned_buf[:int(nbytes)].to(self.device, non_blocking=True)
+        with self.torch.cuda.stream(self.stream_obj):
+            return pinned_buf[:int(nbytes)].to(self.device, non_blocking=True)
 
     def host_visible(self, nbytes: int):
         """(buffer whose ptr() kernels may write, uint8 array over the same memory): page-locked host memory — hipHostMalloc
@@ -296,9 +303,10 @@ class HipBackend(_Base):
 
     def grown(self, buf, used_bytes: int, new_bytes: int):
         """A larger buffer holding the first used_bytes of buf (device-to-device copy)."""
-        new = self.torch.empty(int(new_bytes), dtype=self.torch.uint8, device=self.device)
-        if used_bytes:
-            new[:used_bytes].copy_(buf[:used_bytes])
+        with self.torch.cuda.stream(self.stream_obj):
+            new = self.torch.empty(int(new_bytes), dtype=self.torch.uint8, device=self.device)
+            if used_bytes:
+                new[:used_bytes].copy_(buf[:used_bytes])
         return new
 
     def synchronize(self):

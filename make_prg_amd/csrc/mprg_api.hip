@@ -141,7 +141,10 @@ static int d_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int3
                           int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, uint8_t *gcodes, void *stream,
                           DsCount dc_views, DsCount dc_rows) {
   if (n_views <= 0) return 0;
-  if (n_work_rows > 0) LAUNCH(k_ungap_hash, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, ucodes, hashes, ulen, gcodes, dc_rows);
+  if (n_work_rows > 0) {
+    LAUNCH(k_ungap_hash, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, ucodes, hashes, ulen, gcodes, dc_rows);
+    LAUNCH(k_ungap_hash_u, n_work_rows, UG_ROWS, stream, views, work_rows, (const uint8_t *)ucodes, hashes, (const int32_t *)ulen, dc_rows);
+  }
   LAUNCH(k_ungap_dedupe, n_views, g_dd_threads, stream, arena, views, rowidx, kmer_size, ucodes, (const uint8_t *)gcodes, hashes, ulen, rep_u, rep_g,
          d_of_row, s_of_row, reps_pos, reps_len, seqrow, occ_off, summary, dc_views);
   return check_launch("k_ungap_dedupe");
@@ -665,12 +668,35 @@ int mprg_forest_level(const int64_t *F, void *stream) {
                                                   lst, (int)n_c, stream, slot(b4 + 2 + c));
           if (rc != 0) return -1;
         }
-        // ---- S6 the clustering loop of every problem (cluster_sequences.py:256-274), statistics into the sizes block
-        if (d_cluster_loop(FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_PTAB), (int)cap_p, (int)F[MPRG_F_N_INIT], FP(const double, MPRG_F_UNIFORMS),
-                           (const int32_t *)(uintptr_t)F[MPRG_F_UOFF_HOST], FP(const double, MPRG_F_X), FP(double, MPRG_F_WS),
-                           FP(const int32_t, MPRG_F_D_OF_ROW), FP(const uint8_t, MPRG_F_GCODES), FP(int32_t, MPRG_F_CF_SCRATCH), FP(int32_t, MPRG_F_LABELS),
-                           FP(int32_t, MPRG_F_ASSIGN), FP(double, MPRG_F_KM_INFO), FP(int32_t, MPRG_F_KM_STATUS), FP(int32_t, MPRG_F_NUM_CLUSTERS),
-                           FP(int32_t, MPRG_F_ACTIVE), b4, (int)F[MPRG_F_LOOP_FORMS], stream, dp) != 0) return -1;
+        // ---- S6 the clustering loop of every problem (cluster_sequences.py:256-274), statistics into the sizes block.  The general
+        //      form and the small forms are independent launches: with a side stream (MPRG_F_SIDE_STREAM) they run side by side —
+        //      one form's last, longest problems overlap the other's work
+        {
+          const int forms = (int)F[MPRG_F_LOOP_FORMS];
+          void *side = (void *)(uintptr_t)F[MPRG_F_SIDE_STREAM];
+          const bool split = side && (forms & MPRG_LOOP_GENERAL) && (forms & (MPRG_LOOP_SMALL_LOW | MPRG_LOOP_SMALL_HIGH));
+          hipEvent_t e_fork = nullptr, e_join = nullptr;
+          if (split) {
+            if (hipEventCreateWithFlags(&e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e_join, hipEventDisableTiming) != hipSuccess)
+              return fail("event");
+            hipEventRecord(e_fork, (hipStream_t)stream);
+            hipStreamWaitEvent((hipStream_t)side, e_fork, 0);
+          }
+          auto loop = [&](int which, void *on) {
+            return d_cluster_loop(FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_PTAB), (int)cap_p, (int)F[MPRG_F_N_INIT], FP(const double, MPRG_F_UNIFORMS),
+                                  (const int32_t *)(uintptr_t)F[MPRG_F_UOFF_HOST], FP(const double, MPRG_F_X), FP(double, MPRG_F_WS),
+                                  FP(const int32_t, MPRG_F_D_OF_ROW), FP(const uint8_t, MPRG_F_GCODES), FP(int32_t, MPRG_F_CF_SCRATCH), FP(int32_t, MPRG_F_LABELS),
+                                  FP(int32_t, MPRG_F_ASSIGN), FP(double, MPRG_F_KM_INFO), FP(int32_t, MPRG_F_KM_STATUS), FP(int32_t, MPRG_F_NUM_CLUSTERS),
+                                  FP(int32_t, MPRG_F_ACTIVE), b4, which, on, dp);
+          };
+          if (split) {
+            if (loop(forms & (MPRG_LOOP_GENERAL | MPRG_LOOP_SKIP_SMALL), stream) != 0) return -1;
+            if (loop(forms & (MPRG_LOOP_SMALL_LOW | MPRG_LOOP_SMALL_HIGH), side) != 0) return -1;
+            hipEventRecord(e_join, (hipStream_t)side);
+            hipStreamWaitEvent((hipStream_t)stream, e_join, 0);
+            hipEventDestroy(e_fork); hipEventDestroy(e_join);          // (released by the runtime once the recorded work is done)
+          } else if (loop(forms, stream) != 0) return -1;
+        }
         // ---- S7 MultiClusterNodes and their children
         const KfStep st5{ds, b5};
         const long long cap_ns = F[MPRG_F_NSPLITS];

@@ -48,6 +48,7 @@ for _i, _n in enumerate("DS LEVEL_INDEX MASK MAXRUN STACK IVFLAG IV NIV STATUS I
 (CAP_TCOLS, CAP_NFUSED, CAP_NOTHER, CAP_ITEMS, CAP_NGAP, CAP_NODES, CAP_SROWS, CAP_UBYTES, CAP_SCOLS, CAP_NDD, CAP_WC, CAP_WR, CAP_TABLE, CAP_FLAG,
  CAP_LO, CAP_XD, CAP_WSD) = range(17)
 CAP_CLS, CAP_LDS, CAP_NCHILD, CAP_POOL = 17, 22, 26, 27
+FI["SIDE_STREAM"] = 160
 DS_OVERFLOW, DS_F0, DS_N, DS_NNODES, DS_POOL_USED, DS_LEVEL, DS_NFAILED, DS_GLOBAL, DS_LEVEL_WORDS = 0, 1, 2, 3, 4, 5, 6, 16, 6 * 96
 # levels without host waits once the engine has a plan (the previous forest of the same resident batch): MPRG_SPECULATIVE=0 keeps the
 # per-step host
@@ -289,6 +290,7 @@ class ForestEngine(BatchEngine):
         self._uoffs_host = uoffs
         small = bool(KM_MODE & 2)
         self._set(NODES=self.d_nodes, POOL=self.d_pool, DS=d_ds, UNIFORMS=self._d_uni, LOOP_FORMS=(1 | 8 | 2 | 4) if small else 1)
+        self.F[FI["SIDE_STREAM"]] = be.side_ptr(0) if (small and KM_SIDE_STREAMS and be.n_side_streams >= 1 and be.side_ptr(0) != be.stream) else 0
         self.F[FI["UOFF_HOST"]] = uoffs.ctypes.data
         C = FI["CAP"]
         self.F[C + CAP_NODES], self.F[C + CAP_POOL] = self.cap_nodes, self.pool_cap // 4

@@ -131,3 +131,40 @@ def test_ingest_from_memory_equals_ingest_from_files(lib, tmp_path):
         outs.append((arena.tobytes(), titles.tobytes()))
         lib.mprg_ingest_close_host(h)
     assert outs[0] == outs[1] and outs[0][0].startswith(b"ACGT-NACGTTA") and outs[0][1].startswith(b"a x\nb\n")
+
+
+def test_gzipped_files_are_inflated_by_the_native_parser(lib, tmp_path):
+    """utils/io_utils.py:24-26: a path ending in .gz is read through gzip.  The native batch parser inflates such files itself (one
+    or several gzip members) and hands them on like plain text; a damaged .gz is left to the Python parser (status -3)."""
+    import gzip
+    texts = [b">a x\nACGT-N\n>b\nacgtta\n", b">r1\n" + b"ACGT" * 5000 + b"\n>r2\n" + b"ACGA" * 5000 + b"\n"]
+    paths = []
+    for i, t in enumerate(texts):
+        p = tmp_path / f"g{i}.fa.gz"
+        p.write_bytes(gzip.compress(t))
+        paths.append(p)
+    p = tmp_path / "two_members.fa.gz"
+    p.write_bytes(gzip.compress(b">m1\nACGT\n") + gzip.compress(b">m2\nACGA\n"))
+    paths.append(p)
+    p = tmp_path / "broken.fa.gz"
+    p.write_bytes(gzip.compress(texts[0])[:-9])
+    paths.append(p)
+    p = tmp_path / "plain_magic.fa"          # gzip bytes without the .gz name: not inflated (the reference decides by name)
+    p.write_bytes(gzip.compress(texts[0]))
+    paths.append(p)
+    n = len(paths)
+    blob = b"".join(os.fsencode(str(q)) + b"\0" for q in paths)
+    h = lib.mprg_ingest_open_host(blob, n, 2)
+    info = np.zeros((n, 5), np.int64)
+    lib.mprg_ingest_info_host(h, info.ctypes.data)
+    assert info[:, 0].tolist() == [0, 0, 0, -3, -3]
+    assert info[:3, 1].tolist() == [2, 2, 2] and info[:3, 2].tolist() == [6, 20000, 4] and info[0, 4] & 2
+    ok = info[:, 0] == 0
+    sizes = np.where(ok, info[:, 1] * info[:, 2], 0)
+    raw_off = np.where(ok, np.cumsum(sizes) - sizes, -1)
+    t_off = np.cumsum(np.where(ok, info[:, 3], 0)) - np.where(ok, info[:, 3], 0)
+    arena, titles = np.zeros(int(sizes.sum()) + 1, np.uint8), np.zeros(int(info[ok, 3].sum()) + 1, np.uint8)
+    lib.mprg_ingest_fill_host(h, arena.ctypes.data, raw_off.ctypes.data, titles.ctypes.data, t_off.ctypes.data, 2)
+    lib.mprg_ingest_close_host(h)
+    assert arena.tobytes().startswith(b"ACGT-NACGTTA" + b"ACGT" * 5000 + b"ACGA" * 5000 + b"ACGTACGA")
+    assert titles.tobytes().startswith(b"a x\nb\nr1\nr2\nm1\nm2\n")
