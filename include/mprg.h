@@ -83,8 +83,9 @@ int mprg_compact_columns(const uint8_t *arena, const int64_t *views, const int32
                          int rows_per_chunk, const uint32_t *mask, uint8_t *out, const int64_t *out_off, int32_t *kept, void *stream);
 
 /* A3-A6 — from_msa/interval_partition.py:81-252 (IntervalPartitioner) with utils/seq_utils.py:37-42
- * (has_empty_sequence) and the <2-sequences test of :187-217.  Gap runs: one workgroup per (view, 256-row chunk)
- * — work_rows: n x 2 int32 {view, chunk} —; the interval scan itself: one workgroup per view.
+ * (has_empty_sequence) and the <2-sequences test of :187-217.  Gap runs: one workgroup per (view, 256-row chunk, 2 048-column
+ * segment) — work_rows: n x 2 int32 {view, segment * row chunks of the view + row chunk}, ceil(rows / 256) * ceil(columns / 2048) items
+ * per view —; the interval scan itself: one workgroup per view.
  * in:  mask (from mprg_column_masks), min_match_length.
  * scratch: maxrun uint32[total_cols] (zeroed), stack int32[4*total_cols], ivflag int32[total_cols*2] (zeroed)
  * out: iv int32[3*total_cols] as {start, stop, type} triples at 3*col_off, n_iv int32[n_views],
@@ -106,8 +107,9 @@ int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *ro
                    const int32_t *other_list, int n_other, void *stream);
 
 /* A9a/A13/A16 — from_msa/cluster_sequences.py:220-233 (ungap, group identical rows in first-appearance order),
- * utils/seq_utils.py:58-70 (unique gapped / ungapped counts).  Ungap + hash: one workgroup per (view, 256-row chunk)
- * — work_rows: n x 2 int32 {view, chunk} —, one wavefront per row; grouping: one workgroup per view.
+ * utils/seq_utils.py:58-70 (unique gapped / ungapped counts).  Ungap + hash: one workgroup per (view, row chunk) — work_rows:
+ * n x 2 int32 {view, chunk}; a chunk is 256 rows, 32 for a view of more than 4 096 columns —, one wavefront per row; grouping: one
+ * workgroup per view, after a scan over the same work items for the views of more than 512 rows.
  * views[AUX0] = byte offset (a multiple of 16) of this view's region in `ucodes`: n_rows * upitch bytes, upitch =
  * round_up(n_cols, 16); ungapped codes are stored ROW-MAJOR: character j of row position i at i*upitch + j.
  * per row (at row_off): ulen, rep_u (smallest row position with identical ungapped content), rep_g (same for gapped
@@ -211,6 +213,16 @@ int mprg_argpartition(const double *values, int32_t *perm, int n, int kth, int32
 int mprg_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
                           const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
                           int32_t *km_status, void *stream);
+/* K6 without the sample-sample tables (statistics, centred matrix, norms, the counts as bytes): for problems ALL of whose fits take
+ * mprg_kmeans_fit_wide, which computes the tables' elements where its seeding asks for them.  list: rows of `prob` (NULL: 0..n-1). */
+int mprg_kmeans_prepare_stats(const int64_t *prob, const double *xcounts, double *ws, const int32_t *list, int n_list, void *stream);
+/* the same with a WIDE workgroup (1 024 threads) per restart: for BIG fits — hundreds of distinct sequences x thousands of k-mers, the
+ * clustering problems of one deep alignment — whose phases are thousands of chains as long as the k-mer dictionary: ten workgroups
+ * on ten CUs instead of ten restarts behind one CU's L1 (profiles/r04/deep_alignment.md).  Reads the counts as bytes from the
+ * workspace and none of K6's tables (mprg_kmeans_prepare_stats is enough for its problems; mprg_kmeans_prepare works too). */
+int mprg_kmeans_fit_wide(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
+                         const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
+                         int32_t *km_status, void *stream);
 int mprg_kmeans_wave_class(int64_t D, int64_t V, int k);
 /* A11, the workgroup form for SMALL fits: 128-thread workgroups with a trimmed static LDS (8 KB pool; small_class 0 also a
  * 6 x 6 centre-centre table, i.e. k <= 6), so that 6-8 fits are resident per CU instead of 4.  mprg_kmeans_small_class(D, V, k,
@@ -226,7 +238,8 @@ int mprg_kmeans_fit_wave(const int64_t *prob, const int32_t *kinfo, const int32_
 void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
 
 /* A10 — cluster_sequences.py:59-111 (majority string, Hamming distance, one-reference-like test, cluster_further).
- * Two launches: majority strings per (problem, 256-column tile) — work_cols: n x 2 int32 {problem, tile} — then
+ * Two launches: majority strings per (problem, column tile) — work_cols: n x 2 int32 {problem, tile}; a tile is 256 columns, 32 for a
+ * problem whose view has more than 1 024 rows (MPRG_CF_TILE / _TILE_BIG / _ROWS below) — then
  * Hamming distances per (problem, 256-row chunk) — work_rows: n x 2 int32 {problem, chunk}.
  * A row takes part if d_of_row >= 0; its cluster is labels[prob[LABEL_OFF] + d_of_row] (labels == NULL: a single
  * cluster).  Ties in the per-column majority go to the symbol seen first in the order in which the reference enumerates
@@ -239,6 +252,7 @@ void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
  * read a view as one contiguous block instead of a narrow slice of every alignment row.
  * kinfo (optional, the fit descriptors of that round, problem p = fit p): a problem whose descriptor says k = 0 sat the round out
  * (mprg_forest_kloop_advance) and is skipped here too.  In mprg_kmeans_fit (slot_ws == NULL) a fit with k = 0 returns at once. */
+enum { MPRG_CF_TILE = 256, MPRG_CF_TILE_BIG = 32, MPRG_CF_ROWS = 1024 };
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
                          int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                          const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
@@ -349,6 +363,8 @@ enum {
   MPRG_F_CF_SCRATCH = 118, MPRG_F_TABLE = 119, MPRG_F_FLAG = 120, MPRG_F_X = 121, MPRG_F_WS = 122, MPRG_F_LABELS = 123, MPRG_F_ASSIGN = 124,
   MPRG_F_UNIFORMS = 125, MPRG_F_UOFF_HOST = 126 /* HOST int32 [11] */, MPRG_F_LOOP_FORMS = 127 /* MPRG_LOOP_* */,
   MPRG_F_SIDE_STREAM = 160 /* optional: a second stream; the small forms of the clustering loop run there beside the general form */,
+  MPRG_F_MAX_ROWS = 161 /* optional: an upper bound on the rows of a view of this forest (the largest root; 0: unknown) — launches that only
+                         * views of thousands of rows need are left out below it */,
   MPRG_F_CAP = 128 /* + MPRG_CAP_* */,
   MPRG_F_FIELDS = 192
 };

@@ -41,6 +41,7 @@ static int env_threads(const char *name, int dflt, int hi = 1024) {
 static const int g_pf_threads = env_threads("MPRG_PF_THREADS", BLOCK_VIEW);
 static const int g_dd_threads = env_threads("MPRG_DD_THREADS", BLOCK_VIEW, 512);   // k_ungap_dedupe packs three 10-bit counters per scan
 static const int g_km_threads = env_threads("MPRG_KM_THREADS", 256);
+static const int g_km_wide_threads = env_threads("MPRG_KM_WIDE_THREADS", 1024);
 static const int g_kp_threads = env_threads("MPRG_KP_THREADS", 0);
 
 extern "C" {
@@ -139,11 +140,17 @@ static int d_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int3
                           const int32_t *work_rows, int n_work_rows, uint8_t *ucodes, uint64_t *hashes, int32_t *ulen,
                           int32_t *rep_u, int32_t *rep_g, int32_t *d_of_row, int32_t *s_of_row, int32_t *reps_pos,
                           int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, uint8_t *gcodes, void *stream,
-                          DsCount dc_views, DsCount dc_rows) {
+                          DsCount dc_views, DsCount dc_rows, long long max_rows = 0) {
   if (n_views <= 0) return 0;
   if (n_work_rows > 0) {
     LAUNCH(k_ungap_hash, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, ucodes, hashes, ulen, gcodes, dc_rows);
     LAUNCH(k_ungap_hash_u, n_work_rows, UG_ROWS, stream, views, work_rows, (const uint8_t *)ucodes, hashes, (const int32_t *)ulen, dc_rows);
+    // views of more rows than k_ungap_dedupe's LDS table holds: their row groups by a scan over (view, 256-row chunk) work items.
+    // A list with one chunk per view has no such view; a device-counted list (capacities here) goes by the caller's bound on
+    // the rows of a view (max_rows; 0: none known).
+    if (max_rows > 0 ? max_rows > DD_ROWS : (dc_rows.ds != nullptr || n_work_rows > n_views))
+      LAUNCH(k_dedupe_scan_big, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, (const uint8_t *)ucodes, (const uint64_t *)hashes,
+             (const int32_t *)ulen, rep_u, rep_g, dc_rows);
   }
   LAUNCH(k_ungap_dedupe, n_views, g_dd_threads, stream, arena, views, rowidx, kmer_size, ucodes, (const uint8_t *)gcodes, hashes, ulen, rep_u, rep_g,
          d_of_row, s_of_row, reps_pos, reps_len, seqrow, occ_off, summary, dc_views);
@@ -189,6 +196,11 @@ int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts,
                         int n_lds, int64_t lds_bytes, const int32_t *other_list, int n_other, void *stream) {
   return d_kmeans_prepare(prob, n_probs, xcounts, ws, lds_list, n_lds, lds_bytes, other_list, n_other, stream, DS_HOST);
 }
+int mprg_kmeans_prepare_stats(const int64_t *prob, const double *xcounts, double *ws, const int32_t *list, int n_list, void *stream) {
+  if (n_list <= 0) return 0;
+  LAUNCH(k_kmeans_prepare, n_list, 256, stream, list, prob, xcounts, ws, 1, DS_HOST);
+  return check_launch("k_kmeans_prepare");
+}
 // dc: device count of the ONE list the call holds (device-counted calls pass either lds_list or other_list)
 static int d_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts, double *ws, const int32_t *lds_list,
                             int n_lds, int64_t lds_bytes, const int32_t *other_list, int n_other, void *stream, DsCount dc) {
@@ -197,7 +209,7 @@ static int d_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcou
   else if (n_lds + n_other != n_probs) return fail("mprg_kmeans_prepare: the two problem lists must cover the problems");
   if (n_lds > 0 && (lds_bytes <= 0 || lds_bytes > MPRG_KMEANS_PREPARE_LDS_MAX)) return fail("mprg_kmeans_prepare: lds_bytes out of range");
   if (n_other > 0) {
-    LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws, dc);
+    LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws, 0, dc);
     LAUNCH(k_kmeans_prepare_tables, (long long)n_other * KP_PARTS, 256, stream, other_list, prob, xcounts, ws, dc);
   }
   if (n_lds > 0) {
@@ -246,16 +258,29 @@ int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, const int32_t *fi
   return check_launch("k_kmeans_fit");
 }
 
-int mprg_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
-                          const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
-                          int32_t *km_status, void *stream) {
+static int d_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
+                              const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
+                              int32_t *km_status, int threads, void *stream) {
   if (n_fits <= 0) return 0;
   if (n_init < 1 || n_init > KM_RMAX) return fail("n_init must be 1..16");
-  hipLaunchKernelGGL(k_kmeans_restart_one, dim3((unsigned)((long long)n_fits * n_init)), dim3(64), 0, (hipStream_t)stream, prob, kinfo, fit_list,
-                     n_init, uniforms_dev, xcounts, ws, km_status);
+  if (threads > 64)
+    LAUNCH(k_kmeans_restart_wide, (long long)n_fits * n_init, threads, stream, prob, kinfo, fit_list, n_init, uniforms_dev, xcounts, ws, km_status);
+  else
+    hipLaunchKernelGGL(k_kmeans_restart_one, dim3((unsigned)((long long)n_fits * n_init)), dim3(64), 0, (hipStream_t)stream, prob, kinfo, fit_list,
+                       n_init, uniforms_dev, xcounts, ws, km_status);
   if (check_launch("k_kmeans_restart_one") != 0) return -2;
   LAUNCH(k_kmeans_select_list, n_fits, 256, stream, prob, kinfo, fit_list, n_init, xcounts, ws, labels, km_info);
   return check_launch("k_kmeans_select_list");
+}
+int mprg_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
+                          const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
+                          int32_t *km_status, void *stream) {
+  return d_kmeans_fit_split(prob, kinfo, fit_list, n_fits, n_init, uniforms_dev, xcounts, ws, labels, km_info, km_status, 64, stream);
+}
+int mprg_kmeans_fit_wide(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
+                         const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
+                         int32_t *km_status, void *stream) {
+  return d_kmeans_fit_split(prob, kinfo, fit_list, n_fits, n_init, uniforms_dev, xcounts, ws, labels, km_info, km_status, g_km_wide_threads, stream);
 }
 
 int mprg_kmeans_wave_class(int64_t D, int64_t V, int k) { return (k < 2 || k > KM_KMAX) ? -1 : km_wave_class_host(D, V, k); }
@@ -623,7 +648,7 @@ int mprg_forest_level(const int64_t *F, void *stream) {
                        FP(uint8_t, MPRG_F_UCODES), FP(uint64_t, MPRG_F_HASHES), FP(int32_t, MPRG_F_ULEN), FP(int32_t, MPRG_F_REP_U),
                        FP(int32_t, MPRG_F_REP_G), FP(int32_t, MPRG_F_D_OF_ROW), FP(int32_t, MPRG_F_S_OF_ROW), FP(int32_t, MPRG_F_REPS_POS),
                        FP(int32_t, MPRG_F_REPS_LEN), FP(int32_t, MPRG_F_SEQROW), FP(int64_t, MPRG_F_OCC_OFF), FP(int64_t, MPRG_F_SUMMARY),
-                       FP(uint8_t, MPRG_F_GCODES), stream, slot(b1 + 1), slot(b1 + 5)) != 0) return -1;
+                       FP(uint8_t, MPRG_F_GCODES), stream, slot(b1 + 1), slot(b1 + 5), F[MPRG_F_MAX_ROWS]) != 0) return -1;
     int64_t *b2 = blk(MPRG_STEP_CLUSTER);
     const KfStep st2{ds, b2};
     const long long cap_pq = F[MPRG_F_NPQ];

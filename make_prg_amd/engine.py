@@ -237,6 +237,28 @@ class BatchEngine:
         w[:, 1] = np.arange(total) - np.repeat(np.cumsum(cnt) - cnt, cnt)
         return w
 
+    @staticmethod
+    def _items(cnt: np.ndarray) -> np.ndarray:
+        """{view, item} pairs: cnt[v] items of view v."""
+        total = int(cnt.sum())
+        w = np.empty((total, 2), np.int32)
+        w[:, 0] = np.repeat(np.arange(len(cnt)), cnt)
+        w[:, 1] = np.arange(total) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        return w
+
+    @classmethod
+    def _gap_run_work(cls, tab: np.ndarray) -> np.ndarray:
+        """Work items of mprg_partition's gap-run launch: (256-row chunk, 2 048-column segment) pairs of every view (gr_items,
+        csrc/k_partition.inc)."""
+        return cls._items(((tab[:, 5] + 255) // 256) * ((tab[:, 7] + 2047) // 2048))
+
+    @classmethod
+    def _dedupe_work(cls, tab: np.ndarray) -> np.ndarray:
+        """Work items of mprg_ungap_dedupe: row chunks of 256 rows, 32 for a view of more than 4 096 columns (ug_chunks,
+        csrc/k_rows.inc)."""
+        chunk = np.where(tab[:, 7] > 4096, 32, 256)
+        return cls._items((tab[:, 5] + chunk - 1) // chunk)
+
     # ------------------------------------------------------------------------------------------------ main entry
     def load(self, msas: List[MSA]):
         """Ingest: encode + lay out + upload the batch; afterwards the alignments are resident in HBM."""
@@ -303,7 +325,7 @@ class BatchEngine:
             d_mask = be.upload(given_mask.astype(np.uint32))
         d_maxrun, d_stack, d_ivflag = be.zeros(4 * total_cols), be.empty(16 * total_cols), be.zeros(8 * total_cols)
         d_iv, d_niv, d_status = be.empty(12 * total_cols), be.empty(4 * n), be.empty(4 * n)
-        wr = self._row_chunk_work(tab)
+        wr = self._gap_run_work(tab)
         d_wr = be.upload(wr)
         be.call("mprg_partition", be.ptr(self.d_arena), be.ptr(d_views), be.ptr(d_rowidx), n, be.ptr(d_mask), L,
                 be.ptr(d_wr), len(wr), be.ptr(d_maxrun), be.ptr(d_stack), be.ptr(d_ivflag), be.ptr(d_iv), be.ptr(d_niv),
@@ -389,7 +411,9 @@ class BatchEngine:
             w[:, 1] = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
             return w
 
-        return items((sub[views, 7] + 255) // 256), items((sub[views, 5] + 255) // 256), float((sub[views, 5] * sub[views, 7]).sum())
+        # (column tiles: 256 columns, 32 for a problem of more than 1 024 rows — cf_col_tiles, csrc/k_cluster.inc)
+        tile = np.where(sub[views, 5] > 1024, 32, 256)
+        return items((sub[views, 7] + tile - 1) // tile), items((sub[views, 5] + 255) // 256), float((sub[views, 5] * sub[views, 7]).sum())
 
     def _cluster_further_plan(self, d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further, staged=None,
                               d_gcodes=None):
@@ -444,7 +468,7 @@ class BatchEngine:
                  reps_len=be.empty(4 * R), seqrow=be.empty(4 * R), occ_off=be.empty(8 * (R + n_views)),
                  summary=be.empty(64 * max(n_views, 1)))
         if wr is None:
-            w = self._row_chunk_work(sub)
+            w = self._dedupe_work(sub)
             wr = (be.upload(w), len(w))
         d_wr, n_wr = wr
         be.call("mprg_ungap_dedupe", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(d_rowidx), n_views, self.L,

@@ -49,6 +49,7 @@ for _i, _n in enumerate("DS LEVEL_INDEX MASK MAXRUN STACK IVFLAG IV NIV STATUS I
  CAP_LO, CAP_XD, CAP_WSD) = range(17)
 CAP_CLS, CAP_LDS, CAP_NCHILD, CAP_POOL = 17, 22, 26, 27
 FI["SIDE_STREAM"] = 160
+FI["MAX_ROWS"] = 161
 DS_OVERFLOW, DS_F0, DS_N, DS_NNODES, DS_POOL_USED, DS_LEVEL, DS_NFAILED, DS_GLOBAL, DS_LEVEL_WORDS = 0, 1, 2, 3, 4, 5, 6, 16, 6 * 96
 # levels without host waits once the engine has a plan (the previous forest of the same resident batch): MPRG_SPECULATIVE=0 keeps the
 # per-step host
@@ -64,6 +65,14 @@ KM_SIDE_STREAMS = os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0"
 # a launch list of at most this many fits goes through the SPLIT form (a workgroup per restart + a selection launch,
 # mprg_kmeans_fit_split): such a launch lasts one fit latency whatever it holds (profiles/r03/kmeans_split.md); 0 = never
 KM_SPLIT_BELOW = int(os.environ.get("MPRG_KM_SPLIT_BELOW", "0"))
+# BIG clustering problems (a count matrix of at least this many bytes: hundreds of distinct sequences x thousands of k-mers — what one
+# deep alignment's levels hold, BASELINE config D's stress): their level runs the per-round loop and the general-form fits of its rounds
+# take a wide workgroup per RESTART (mprg_kmeans_fit_wide) — every phase of such a fit is thousands of chains as long as the k-mer
+# dictionary, ten restarts side by side in one workgroup queue behind one CU (profiles/r04/deep_alignment.md); 0 = never
+KM_BIG_BYTES = int(os.environ.get("MPRG_KM_BIG_BYTES", str(1 << 20)))
+# ... and from this size on the level's big problems are prepared WITHOUT the sample-sample tables of the seeding (mprg_kmeans_prepare_stats:
+# 2.5 D^2 chains per problem); the wide fits then compute the few dozen rows they ask for themselves
+KM_NO_TABLES_BYTES = int(os.environ.get("MPRG_KM_NO_TABLES_BYTES", str(160 << 20)))
 # the clustering loop: "fused" = a problem's workgroup walks k = 2..10 itself (mprg_cluster_loop; one launch per workgroup form and
 # level), "rounds" = one set of launches per round k (the shape of rounds 1-3)
 # "auto" (default): fused below KLOOP_ROUNDS_FROM alignments in the engine, rounds from there on.  Measured on MI355X (profiles/r04/
@@ -187,12 +196,15 @@ class ForestEngine(BatchEngine):
     def _forest_exact(self):
         """The per-step host: every step's totals read back; writes the plan the next forest of this batch is sized from."""
         self._plan_rec = []
+        self._big_seen = False
         f0, n = 0, len(self.ok)
         while n:
             self.counters["levels"] += 1
             f0, n = self._forest_level(f0, n)
             self._alive = {k: v for k, v in self._alive.items() if k in ("NODES", "META", "FAILED", "ERR_FIRST", "POOL", "ARENA", "HDR", "HDR_HOST")}
-        self._plan = dict(key=self._roots_args[2], levels=self._plan_rec, n_nodes=self.n_nodes, pool_used=self.pool_used) if self.kloop_fused else None
+        # (a plan is the sizes of a forest whose clustering loops are the fused ones: none for a batch with BIG problems)
+        self._plan = dict(key=self._roots_args[2], levels=self._plan_rec, n_nodes=self.n_nodes, pool_used=self.pool_used) \
+            if (self.kloop_fused and not self._big_seen) else None
 
     def _forest_begin(self, root_levels, forced, key):
         """Node table with the roots, row pool, per-locus flags, state fields.  What depends only on the resident batch (roots,
@@ -292,6 +304,7 @@ class ForestEngine(BatchEngine):
         self._set(NODES=self.d_nodes, POOL=self.d_pool, DS=d_ds, UNIFORMS=self._d_uni, LOOP_FORMS=(1 | 8 | 2 | 4) if small else 1)
         self.F[FI["SIDE_STREAM"]] = be.side_ptr(0) if (small and KM_SIDE_STREAMS and be.n_side_streams >= 1 and be.side_ptr(0) != be.stream) else 0
         self.F[FI["UOFF_HOST"]] = uoffs.ctypes.data
+        self.F[FI["MAX_ROWS"]] = int(self.meta_arr[self.ok, 4].max()) if len(self.ok) else 1          # no view has more rows than its root
         C = FI["CAP"]
         self.F[C + CAP_NODES], self.F[C + CAP_POOL] = self.cap_nodes, self.pool_cap // 4
         reps = []
@@ -504,6 +517,7 @@ class ForestEngine(BatchEngine):
                 be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_x), be.stream)
         # mprg_kmeans_prepare, one launch per class of LDS need (every workgroup of a launch allocates the launch's lds_bytes)
         prep_work = 8.0 * x_doubles
+        big_level = bool(KM_BIG_BYTES) and int(h[16:17 + PREPARE_CLASSES].max()) >= KM_BIG_BYTES          # (the level's largest count matrix + means)
         for c in range(PREPARE_CLASSES + 1):
             n_c = int(h[2 + c])
             if not n_c:
@@ -512,6 +526,8 @@ class ForestEngine(BatchEngine):
             if c < PREPARE_CLASSES:
                 be.call("mprg_kmeans_prepare", be.ptr(d_ptab), n_c, be.ptr(d_x), be.ptr(d_ws), lst, n_c, int(h[16 + c]), 0, 0, be.stream,
                         work=prep_work)
+            elif big_level and int(h[16 + PREPARE_CLASSES]) >= KM_NO_TABLES_BYTES:          # (their fits take mprg_kmeans_fit_wide below)
+                be.call("mprg_kmeans_prepare_stats", be.ptr(d_ptab), be.ptr(d_x), be.ptr(d_ws), lst, n_c, be.stream, work=prep_work)
             else:
                 be.call("mprg_kmeans_prepare", be.ptr(d_ptab), n_c, be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, lst, n_c, be.stream, work=prep_work)
             prep_work = 0.0
@@ -521,7 +537,12 @@ class ForestEngine(BatchEngine):
         #      host wait per round.  The general form and the small forms are independent launches: side by side on a side stream.
         #      MPRG_KLOOP=rounds keeps the per-round launches of rounds 1-3 (k_kl_advance + fit lists + mprg_cluster_further).
         km_events, cf_events = [], []
-        if self.kloop_fused:
+        big = big_level
+        self.counters["max_problem_bytes"] = max(int(self.counters.get("max_problem_bytes", 0)), int(h[16:17 + PREPARE_CLASSES].max()))
+        if big:
+            self._big_seen = True
+        fused = self.kloop_fused and not big
+        if fused:
             uoffs = np.zeros(MAX_CLUSTERS + 1, np.int32)
             for k_, o_ in self._uoff.items():
                 uoffs[k_] = o_
@@ -544,7 +565,7 @@ class ForestEngine(BatchEngine):
             self.counters["launches"] += 2 if small else 1
         else:
             self._kloop_rounds(P, d_sub, d_ptab, d_kinfo, d_x, d_ws, d_labels, d_assign, d_info, d_st, d_wc, n_wc, d_wr, n_wr, d_scratch,
-                               d_further, dd, km_events, cf_events)
+                               d_further, dd, km_events, cf_events, wide=big)
         # ---- S7: MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
         self._scratch(P)
         h = self._step("splits_count", n_hdr=HDR)
@@ -554,7 +575,7 @@ class ForestEngine(BatchEngine):
         kb = {"mprg_kmeans_fit_wave": float(h[81:82].view(np.float64)[0]), "mprg_kmeans_fit": float(h[85:86].view(np.float64)[0]),
               "mprg_kmeans_fit_small": float(h[93:94].view(np.float64)[0])}
         km_bytes = sum(kb.values())
-        if self.kloop_fused:          # a fused launch's algorithmic bytes: its fits' 8 D V (iterations + n_init) + the cells its cluster_further visits
+        if fused:          # a fused launch's algorithmic bytes: its fits' 8 D V (iterations + n_init) + the cells its cluster_further visits
             kb = {LOOP_GENERAL: kb["mprg_kmeans_fit"], LOOP_SMALL: kb["mprg_kmeans_fit_small"]}
             kb[LOOP_SMALL if (KM_MODE & 2) else LOOP_GENERAL] += cf_cells
         if h[82]:
@@ -585,7 +606,7 @@ class ForestEngine(BatchEngine):
 
 
     def _kloop_rounds(self, P, d_sub, d_ptab, d_kinfo, d_x, d_ws, d_labels, d_assign, d_info, d_st, d_wc, n_wc, d_wr, n_wr, d_scratch,
-                      d_further, dd, km_events, cf_events):
+                      d_further, dd, km_events, cf_events, wide=False):
         """The clustering loop as one set of launches per round k (rounds 1-3's shape; MPRG_KLOOP=rounds): the control step settles
         the previous round on the device (k_kl_advance), a retired problem's workgroups return at once."""
         be = self.be
@@ -610,8 +631,8 @@ class ForestEngine(BatchEngine):
                 lst = be.ptr(d_fl) + 4 * c * P
                 stream = be.side_ptr(q) if n_side else be.stream
                 outs = out_args[:-1] + (stream,)
-                if n_c <= KM_SPLIT_BELOW:
-                    entry = "mprg_kmeans_fit_split"
+                if (wide and cls is None) or n_c <= KM_SPLIT_BELOW:          # (wide: a level with BIG problems, its general-form fits)
+                    entry = "mprg_kmeans_fit_wide" if (wide and cls is None) else "mprg_kmeans_fit_split"
                     be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, *outs, side=q if n_side else None)
                 elif cls is None:
                     be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, 0, 0, 0, 0, *outs, side=q if n_side else None)
@@ -619,7 +640,7 @@ class ForestEngine(BatchEngine):
                     be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, cls, N_INIT, *fit_args, *outs, side=q if n_side else None)
                 ev = self._last_event(entry)
                 km_events.append(ev and ev + (list_entry,))
-                self.counters["launches"] += 1 + (entry == "mprg_kmeans_fit_split")
+                self.counters["launches"] += 1 + (entry in ("mprg_kmeans_fit_split", "mprg_kmeans_fit_wide"))
             if n_side:
                 be.join(n_side)
             self._cluster_further(d_sub, d_ptab, P, k, dd, d_labels, d_assign, d_wc, n_wc, d_wr, n_wr, d_scratch, d_further, d_info, d_kinfo)

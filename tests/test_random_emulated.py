@@ -49,6 +49,69 @@ def test_wide_views_take_the_fallback_paths(emu, N, L, S, C, p, monkeypatch):
     pc.check_vs_oracle(emu, [_wide_fasta(100 + C, S, C, p)], N, L)
 
 
+def test_gap_runs_reach_across_column_segments(emu, monkeypatch):
+    """k_gap_runs splits a wide view into 2 048-column segments: a run that begins before a segment (or covers whole segments) is
+    counted backwards from the segment's start.  Rows with gap stretches across columns 2 048 and 4 096, variation inside them."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    C = 4400
+    base = rng.integers(0, 4, C)
+    rows = []
+    for i in range(6):
+        y = np.frombuffer(b"ACGT", np.uint8)[base].copy()
+        for c in (1990, 2040, 2100, 3000, 4090, 4100, 4300):          # variation: non-match columns inside and next to the stretches
+            y[c] = b"ACGT"[(int(base[c]) + 1 + i % 3) % 4]
+        rows.append(y)
+    rows[1][2030:2060] = ord("-")          # across the first boundary
+    rows[2][1985:4200] = ord("-")          # a whole segment and both boundaries
+    rows[4][4096:4110] = ord("-")          # begins exactly at a boundary
+    rows[5][4080:4096] = ord("-")          # ends exactly before one
+    text = "".join(f">g{i}\n{r.tobytes().decode()}\n" for i, r in enumerate(rows))
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    for N, L in ((3, 7), (2, 3)):
+        pc.check_vs_oracle(emu, [text], N, L)
+
+
+def test_big_view_row_groups_when_every_hash_collides(monkeypatch):
+    """More rows than k_ungap_dedupe's LDS table holds: k_dedupe_scan_big decides by symbols behind the hash filter — here with the
+    test-only hash that only counts symbols, so most candidates pass the filter and differ."""
+    import numpy as np
+    weak = EmuBackend(defines=("MPRG_TEST_WEAK_HASH",), tag="_weakhash")
+    rng = np.random.default_rng(9)
+    C = 40
+    variants = [rng.integers(0, 4, C) for _ in range(9)]
+    rows = [variants[int(rng.integers(0, len(variants)))].copy() for _ in range(700)]
+    txt = [np.frombuffer(b"ACGT", np.uint8)[r].copy() for r in rows]
+    for i in range(0, 700, 7):
+        txt[i][5:8] = ord("-")          # gapped twins of ungapped-different rows, and the reverse
+    text = "".join(f">b{i}\n{t.tobytes().decode()}\n" for i, t in enumerate(txt))
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    pc.check_vs_oracle(weak, [text], 4, 5)
+
+
+def test_leaf_of_many_alleles_is_laid_out_by_its_wavefront(emu, monkeypatch):
+    """k_as_leaf_jobs: a leaf of more than 128 alleles (here the child of a root at the nesting limit, 300 and 90 distinct rows in one
+    batch so that big and small leaves share wavefronts) gets its alleles' places from a wavefront prefix sum."""
+    import numpy as np
+    rng = np.random.default_rng(21)
+    texts = []
+    for S in (300, 90, 200):
+        C = 30
+        base = rng.integers(0, 4, C)
+        rows = []
+        for i in range(S):
+            y = base.copy()
+            y[5:25] = rng.integers(0, 4, 20)
+            t = np.frombuffer(b"ACGT", np.uint8)[y].copy()
+            if i % 5 == 0:
+                t[10:10 + i % 7] = ord("-")          # alleles of different lengths
+            rows.append(t.tobytes().decode())
+        texts.append("".join(f">a{i}\n{r}\n" for i, r in enumerate(rows)))
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    eng = pc.check_vs_oracle(emu, texts, 1, 7)
+    assert int(eng.tab["nseq"].max()) > 128
+
+
 def test_tall_view_takes_the_unbucketed_majority_path(emu, monkeypatch):
     """More rows than the LDS member lists of k_cluster_majority hold (CF_ROWS)."""
     import numpy as np
@@ -108,3 +171,20 @@ def test_clustering_loop_forms_agree(monkeypatch, golden_integration):
     monkeypatch.setattr(F, "KLOOP", "rounds")
     pc.check_vs_oracle(EmuBackend(), random_cases(42, 40), 5, 7)
     assert pc.check_integration(EmuBackend(), golden_integration) >= 30
+
+
+def test_levels_with_big_problems_take_the_wide_fits(emu, monkeypatch, golden_integration):
+    """forest.KM_BIG_BYTES: a level whose largest count matrix reaches it runs the per-round loop with a wide workgroup per restart
+    for its general-form fits (mprg_kmeans_fit_wide) — here every level (threshold 1 byte), in an engine whose loop is otherwise the
+    fused one; no plan is kept for such a batch.  Same answers as the oracle / the real reference's goldens."""
+    import make_prg_amd.forest as F
+    monkeypatch.setattr(F, "KM_BIG_BYTES", 1)
+    monkeypatch.setattr(F, "KM_MODE", 0)          # (every fit through the general form)
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    eng = pc.check_vs_oracle(emu, random_cases(51, 24), 5, 7)
+    assert eng._big_seen and eng._plan is None
+    assert pc.check_integration(emu, golden_integration) >= 30
+    # the same with the wide workgroups reading the counts as bytes from the workspace (test-only build: no fit "fits the LDS pool")
+    glob = EmuBackend(defines=("MPRG_TEST_WIDE_GLOBAL",), tag="_wideglobal")
+    pc.check_vs_oracle(glob, random_cases(52, 24), 5, 7)
+    assert pc.check_integration(glob, golden_integration) >= 30

@@ -14,12 +14,17 @@ from bench import make_batch
 from make_prg_amd.backend import HipBackend
 import make_prg_amd.forest as F
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "deep" else 2048
 lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "make_prg_amd", "_lib", "libmprg_hip_timing.so")
-msas = make_batch(list(range(n)), 16)[1]
+if len(sys.argv) > 1 and sys.argv[1] == "deep":          # python tools/phase_timing.py deep S C: one hierarchical alignment (-N 7)
+    from make_prg_amd.msa import MSA, Record
+    from make_prg_amd.utils.synthetic import synth_rows_deep
+    msas = [MSA([Record(r, f"s{i}", f"s{i}") for i, r in enumerate(synth_rows_deep(0, int(sys.argv[2]), int(sys.argv[3])))])]
+else:
+    msas = make_batch(list(range(n)), 16)[1]
 be = HipBackend(0, lib_path=lib)
 print('loop:', F.KLOOP)
-eng = F.ForestEngine(be, 5, 7)
+eng = F.ForestEngine(be, 7 if len(msas) == 1 else 5, 7)
 eng.load(msas)
 eng.run_forest()
 be.synchronize()
