@@ -148,6 +148,11 @@ int mprg_kmer_dictionary(const int64_t *views, const int64_t *prob, int n_probs,
 int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size, const uint8_t *ucodes,
                      const int32_t *ulen, const int32_t *seqrow, const int64_t *occ_off, const uint8_t *table,
                      double *xcounts, void *stream);
+/* the same with `parts` workgroups per problem sharing its occurrences (1..1024): for levels that hold a problem of millions of
+ * k-mer occurrences (the top of one deep alignment), whose single workgroup would otherwise decide the launch's duration */
+int mprg_kmer_counts_parts(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size, const uint8_t *ucodes,
+                     const int32_t *ulen, const int32_t *seqrow, const int64_t *occ_off, const uint8_t *table,
+                     double *xcounts, int parts, void *stream);
 
 /* A11 — the reference's KMeans(n_clusters=k, random_state=2, algorithm="elkan").fit(X).predict(X)
  * (cluster_sequences.py:262-266; arithmetic restated from scikit-learn, see oracle/kmeans_oracle.c) with

@@ -175,14 +175,20 @@ int mprg_kmer_dictionary(const int64_t *views, const int64_t *prob, int n_probs,
   return check_launch("k_kmer_dictionary");
 }
 
-int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size, const uint8_t *ucodes,
-                     const int32_t *ulen, const int32_t *seqrow, const int64_t *occ_off, const uint8_t *table,
-                     double *xcounts, void *stream) {
+int mprg_kmer_counts_parts(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size, const uint8_t *ucodes,
+                           const int32_t *ulen, const int32_t *seqrow, const int64_t *occ_off, const uint8_t *table,
+                           double *xcounts, int parts, void *stream) {
   (void)ulen;
   if (n_probs <= 0) return 0;
   if (kmer_size < 1) return fail("k-mer size must be positive");
-  LAUNCH(k_kmer_counts, n_probs, 512, stream, views, prob, kmer_size, ucodes, seqrow, occ_off, table, xcounts, DS_HOST);
+  if (parts < 1 || parts > 1024) return fail("mprg_kmer_counts_parts: parts must be 1..1024");
+  LAUNCH2(k_kmer_counts, n_probs, parts, 512, stream, views, prob, kmer_size, ucodes, seqrow, occ_off, table, xcounts, DS_HOST);
   return check_launch("k_kmer_counts");
+}
+int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size, const uint8_t *ucodes,
+                     const int32_t *ulen, const int32_t *seqrow, const int64_t *occ_off, const uint8_t *table,
+                     double *xcounts, void *stream) {
+  return mprg_kmer_counts_parts(views, prob, n_probs, kmer_size, ucodes, ulen, seqrow, occ_off, table, xcounts, 1, stream);
 }
 
 int64_t mprg_kmeans_workspace_doubles(int64_t D, int64_t V, int k_max, int n_restart_slots) {

@@ -21,6 +21,9 @@
   hipLaunchKernelGGL(name, dim3((unsigned)(nblocks)), dim3((unsigned)(nthreads)), 0, (hipStream_t)(stream), __VA_ARGS__)
 #define LAUNCH_LDS(name, nblocks, nthreads, lds_bytes, stream, ...) \
   hipLaunchKernelGGL(name, dim3((unsigned)(nblocks)), dim3((unsigned)(nthreads)), (size_t)(lds_bytes), (hipStream_t)(stream), __VA_ARGS__)
+// a (nx, ny) grid: blockIdx.y = which PART of item blockIdx.x's work the workgroup takes (kernels whose items can be huge)
+#define LAUNCH2(name, nx, ny, nthreads, stream, ...) \
+  hipLaunchKernelGGL(name, dim3((unsigned)(nx), (unsigned)(ny)), dim3((unsigned)(nthreads)), 0, (hipStream_t)(stream), __VA_ARGS__)
 #define BLOCK_ID ((int)blockIdx.x)
 #define N_THREADS ((int)blockDim.x)
 // MPRG_TID: the thread's index as PAR_FOR / ONE_THREAD see it — a FRESH copy at every use (one v_mov the compiler cannot see

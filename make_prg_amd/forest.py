@@ -513,11 +513,15 @@ class ForestEngine(BatchEngine):
         self._set(PTAB=d_ptab, CLS_LISTS=d_cls, NUM_CLUSTERS=d_numcl, ACTIVE=d_active, KINFO=d_kinfo, KM_INFO=d_info, KM_STATUS=d_st,
                   FURTHER=d_further, WORK_COLS=d_wc, WORK_ROWS=d_wr)
         self._step("sizes_fill")
-        be.call("mprg_kmer_counts", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
-                be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_x), be.stream)
+        big_level = bool(KM_BIG_BYTES) and int(h[16:17 + PREPARE_CLASSES].max()) >= KM_BIG_BYTES          # (the level's largest count matrix + means)
+        if big_level:          # (a big problem's occurrences — 10^8 at the top of one deep alignment — over many workgroups)
+            be.call("mprg_kmer_counts_parts", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
+                    be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_x), 128, be.stream)
+        else:
+            be.call("mprg_kmer_counts", be.ptr(d_sub), be.ptr(d_ptab), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
+                    be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_x), be.stream)
         # mprg_kmeans_prepare, one launch per class of LDS need (every workgroup of a launch allocates the launch's lds_bytes)
         prep_work = 8.0 * x_doubles
-        big_level = bool(KM_BIG_BYTES) and int(h[16:17 + PREPARE_CLASSES].max()) >= KM_BIG_BYTES          # (the level's largest count matrix + means)
         for c in range(PREPARE_CLASSES + 1):
             n_c = int(h[2 + c])
             if not n_c:

@@ -103,7 +103,7 @@ def test_close_and_regrowth_release_what_the_backend_owns():
         hb, _ = be.pinned(1 << 20, "arena")
         first = hb.mprg_addr
         hb2, arr2 = be.pinned(4 << 20, "arena")                 # outgrown: the old block goes
-        assert hfreed == [first] and hb2.mprg_addr != first and arr2.size >= 4 << 20
+        assert hfreed == [first] and arr2.size >= 4 << 20          # (the emulation's malloc may hand the freed address out again)
         assert be.host_visible(768)[0] is be.host_visible(768)[0]
         be.async_depth = 2
         d = be.upload(np.arange(4 << 18, dtype=np.int64))
