@@ -21,7 +21,7 @@ def pmc(name):
 fetch, write = pmc("pmc_FETCH_SIZE.csv.gz"), pmc("pmc_WRITE_SIZE.csv.gz")
 # cells each kernel visits in the config-D build (root view + its one child view, S x C each; the child is the selected view)
 ALG = {"k_column_masks": 2 * cells, "k_gap_runs": 2 * cells, "k_partition": 2 * cells, "k_ungap_hash": cells, "k_ungap_hash_u": cells,
-       "k_ungap_dedupe": cells, "k_cluster_majority": cells, "k_cluster_hamming": cells, "k_emit_alleles": None, "k_ingest": cells}
+       "k_ungap_dedupe": cells, "k_dedupe_scan_big": None, "k_cluster_majority": cells, "k_cluster_hamming": cells, "k_emit_alleles": None, "k_ingest": cells}
 rows = []
 for n, (calls, ns) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
     if not n.startswith("k_") or ns < 50_000:
