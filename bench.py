@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="alignments for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-deep-leg", action="store_true", help="skip the one-deep-alignment leg (N=1 only)")
     ap.add_argument("--workers", type=int, default=4, help="host worker processes per GPU (each owns a sub-batch); capped by the "
                                                            "CPUs this rank may use")
     ap.add_argument("--streams", type=int, default=0, help="engines (sub-batches on HIP streams of their own, fed by ONE host thread) per worker "
@@ -523,7 +524,7 @@ def main():
     if rank == 0 and world == 1 and W > 1 and not args.no_single_worker_leg:
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--workers", "1", "--steps", str(max(3, args.steps // 2)), "--warmup", "2",
-               "--batch", str(args.batch), "--no-cpu-baseline", "--no-end-to-end", "--no-single-worker-leg", "--no-cli-leg"]
+               "--batch", str(args.batch), "--no-cpu-baseline", "--no-end-to-end", "--no-single-worker-leg", "--no-cli-leg", "--no-deep-leg"]
         try:
             line = subprocess.run(cmd, capture_output=True, text=True, timeout=900, check=True).stdout.strip().splitlines()[-1]
             one = json.loads(line)
@@ -546,7 +547,7 @@ def main():
             entry = dict(n_gpus=n_gpus, alignments_per_step=shard)
             for label, w in (("one_worker", "1"), ("default_workers", "4")):
                 cmd = [sys.executable, os.path.abspath(__file__), "--workers", w, "--steps", "6", "--warmup", "2", "--batch", str(shard),
-                       "--no-cpu-baseline", "--no-end-to-end", "--no-single-worker-leg", "--no-cli-leg", "--no-shard-projection"]
+                       "--no-cpu-baseline", "--no-end-to-end", "--no-single-worker-leg", "--no-cli-leg", "--no-shard-projection", "--no-deep-leg"]
                 try:
                     line = subprocess.run(cmd, capture_output=True, text=True, timeout=900, check=True).stdout.strip().splitlines()[-1]
                     one = json.loads(line)
@@ -612,6 +613,33 @@ def main():
             cli = dict(cli or {}, error=f"{type(err).__name__}: {err}"[:400])
         shutil.rmtree(cli_root, ignore_errors=True)
 
+    # ---- one DEEP alignment (BASELINE config 4's kind of work at the size the parity fixture pins: tests/golden/ddeep.json, 2 000 x 4 000
+    #      hierarchical, -N 7: ~10^4 nodes, ~4 000 KMeans fits of up to 817 sequences x 16 354 k-mers): wall of forest + PRG text in a child
+    #      process, the PRG's hash against the fixture's (the real reference's PRG)
+    deep = None
+    if not args.no_deep_leg and rank == 0 and world == 1:
+        import subprocess
+        import tempfile
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ddeep.json")))
+            with tempfile.TemporaryDirectory() as td:
+                outj = os.path.join(td, "deep.json")
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "deep_profile.py"), str(gold["S"]), str(gold["C"]), str(gold["N"]),
+                                    "--passes", "2"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, MPRG_DEEP_OUT=outj))
+                if r.returncode != 0:
+                    raise RuntimeError(r.stderr[-400:])
+                dj = json.load(open(outj))
+            ps = dj["passes"]
+            deep = dict(workload=f"one hierarchical alignment {gold['S']} x {gold['C']} (utils/synthetic.synth_rows_deep seed {gold['seed']}), -N {gold['N']} -L {gold['L']}",
+                        seconds=round(min(p_["wall_ms"] for p_ in ps) / 1e3, 3), nodes=ps[-1]["nodes"], levels=ps[-1]["levels"], kmeans_fits=ps[-1]["fits"],
+                        prg_identical_to_the_fixture=all(p_["prg_sha256"] == gold["expect"]["prg_sha256"] for p_ in ps),
+                        fixture="tests/golden/ddeep.json (PRG confirmed by the REAL reference: 293 s on this container's CPU)",
+                        top_entry_points=[(e_["entry_point"], e_["ms"]) for e_ in ps[0].get("entry_points", [])[:4]],
+                        region="resident alignment -> recursion forest (per-step host) + PRG text in pinned memory; levels with big clustering "
+                               "problems take mprg_kmeans_fit_wide (profiles/r04/deep_alignment.md)")
+        except Exception as err:          # reported, not hidden
+            deep = dict(error=f"{type(err).__name__}: {err}"[:400])
+
     # whole-job counters (strong scaling: a rank's workers only saw its shard)
     keys = ("launches", "fits", "cells_all", "cells_clustered", "kmeans_bytes", "syncs")
     cvec = torch.tensor([float(counters.get(k_, 0)) for k_ in keys], dtype=torch.float64, device=device if (dist_backend == "nccl" and world > 1) else "cpu")
@@ -670,7 +698,7 @@ def main():
                                    "SURVEY.md §8d generator, seeds 0..batch-1), -N 5 -L 7; one step = every alignment of the job, "
                                    "resident, sharded over the ranks by size (--weak: all of them on every rank)",
                        "alignments_per_step": msas_per_step, "alignments_rank0": len(seeds), "parallelism": f"shard{world}",
-                       "host_worker_processes_per_gpu": W, "cpus_rank0": ncpu, "shard_projection": projection, "km_side_streams": os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0", "single_worker": single, "cli": cli,
+                       "host_worker_processes_per_gpu": W, "cpus_rank0": ncpu, "shard_projection": projection, "km_side_streams": os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0", "single_worker": single, "cli": cli, "deep_alignment": deep,
                        "streams_per_worker": args.streams, "event_timing_in_timed_region": bool(args.profile_timed),
                        "step_includes": "recursion forest (kernels + device-side bookkeeping; the host sizes buffers from one header per "
                                         "step) + PRG text laid out and written on the device + its copy to pinned host memory",

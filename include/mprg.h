@@ -218,16 +218,21 @@ int mprg_argpartition(const double *values, int32_t *perm, int n, int kth, int32
 int mprg_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
                           const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
                           int32_t *km_status, void *stream);
-/* K6 without the sample-sample tables (statistics, centred matrix, norms, the counts as bytes): for problems ALL of whose fits take
- * mprg_kmeans_fit_wide, which computes the tables' elements where its seeding asks for them.  list: rows of `prob` (NULL: 0..n-1). */
-int mprg_kmeans_prepare_stats(const int64_t *prob, const double *xcounts, double *ws, const int32_t *list, int n_list, void *stream);
-/* the same with a WIDE workgroup (1 024 threads) per restart: for BIG fits — hundreds of distinct sequences x thousands of k-mers, the
- * clustering problems of one deep alignment — whose phases are thousands of chains as long as the k-mer dictionary: ten workgroups
- * on ten CUs instead of ten restarts behind one CU's L1 (profiles/r04/deep_alignment.md).  Reads the counts as bytes from the
- * workspace and none of K6's tables (mprg_kmeans_prepare_stats is enough for its problems; mprg_kmeans_prepare works too). */
+/* K6 for BIG problems, whose fits all take mprg_kmeans_fit_wide: statistics, centred matrix, norms — and
+ *   xbytes (optional): the raw counts as BYTES, rows of pitch round_up(V, 4) made an odd number of 4-byte words, problem p at byte
+ *     8 * prob[p][X_OFF] of a buffer as large as xcounts; what the wide fits stream instead of the centred doubles (an eighth of the bytes);
+ *   with_tables = 0: the sample-sample tables of the seeding are NOT made (2.5 D^2 chains per problem) — the wide fits compute the few
+ *     dozen rows they ask for; only mprg_kmeans_fit_wide may fit such a problem.
+ * list: rows of `prob` (NULL: 0..n-1). */
+int mprg_kmeans_prepare_big(const int64_t *prob, const double *xcounts, double *ws, const int32_t *list, int n_list, uint8_t *xbytes,
+                            int with_tables, void *stream);
+/* mprg_kmeans_fit_split with a WIDE workgroup (1 024 threads) per restart: for BIG fits — hundreds to thousands of distinct sequences x
+ * thousands of k-mers, the clustering problems of one deep alignment — whose phases are thousands of chains as long as the k-mer
+ * dictionary: ten workgroups on ten CUs instead of ten restarts behind one CU's L1 (profiles/r04/deep_alignment.md).
+ * xbytes (optional): the byte matrix mprg_kmeans_prepare_big wrote for these problems. */
 int mprg_kmeans_fit_wide(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
                          const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
-                         int32_t *km_status, void *stream);
+                         int32_t *km_status, const uint8_t *xbytes, void *stream);
 int mprg_kmeans_wave_class(int64_t D, int64_t V, int k);
 /* A11, the workgroup form for SMALL fits: 128-thread workgroups with a trimmed static LDS (8 KB pool; small_class 0 also a
  * 6 x 6 centre-centre table, i.e. k <= 6), so that 6-8 fits are resident per CU instead of 4.  mprg_kmeans_small_class(D, V, k,

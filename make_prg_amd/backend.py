@@ -37,8 +37,8 @@ SIGNATURES = {
     "mprg_kmeans_fit": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int64, c_int] + [c_void_p] * 5),
     "mprg_argpartition": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mprg_kmeans_fit_split": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7),
-    "mprg_kmeans_prepare_stats": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
-    "mprg_kmeans_fit_wide": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7),
+    "mprg_kmeans_prepare_big": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_int, c_void_p]),
+    "mprg_kmeans_fit_wide": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8),
     "mprg_kmeans_wave_class": (c_int, [c_int64, c_int64, c_int]),
     "mprg_kmeans_fit_wave": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7),
     "mprg_kmeans_small_class": (c_int, [c_int64, c_int64, c_int, c_int]),

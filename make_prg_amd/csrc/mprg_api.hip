@@ -202,9 +202,11 @@ int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts,
                         int n_lds, int64_t lds_bytes, const int32_t *other_list, int n_other, void *stream) {
   return d_kmeans_prepare(prob, n_probs, xcounts, ws, lds_list, n_lds, lds_bytes, other_list, n_other, stream, DS_HOST);
 }
-int mprg_kmeans_prepare_stats(const int64_t *prob, const double *xcounts, double *ws, const int32_t *list, int n_list, void *stream) {
+int mprg_kmeans_prepare_big(const int64_t *prob, const double *xcounts, double *ws, const int32_t *list, int n_list, uint8_t *xbytes,
+                            int with_tables, void *stream) {
   if (n_list <= 0) return 0;
-  LAUNCH(k_kmeans_prepare, n_list, 256, stream, list, prob, xcounts, ws, 1, DS_HOST);
+  LAUNCH(k_kmeans_prepare, n_list, 256, stream, list, prob, xcounts, ws, with_tables ? 0 : 1, xbytes, DS_HOST);
+  if (with_tables) LAUNCH(k_kmeans_prepare_tables, (long long)n_list * KP_PARTS, 256, stream, list, prob, xcounts, ws, DS_HOST);
   return check_launch("k_kmeans_prepare");
 }
 // dc: device count of the ONE list the call holds (device-counted calls pass either lds_list or other_list)
@@ -215,7 +217,7 @@ static int d_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcou
   else if (n_lds + n_other != n_probs) return fail("mprg_kmeans_prepare: the two problem lists must cover the problems");
   if (n_lds > 0 && (lds_bytes <= 0 || lds_bytes > MPRG_KMEANS_PREPARE_LDS_MAX)) return fail("mprg_kmeans_prepare: lds_bytes out of range");
   if (n_other > 0) {
-    LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws, 0, dc);
+    LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws, 0, (uint8_t *)nullptr, dc);
     LAUNCH(k_kmeans_prepare_tables, (long long)n_other * KP_PARTS, 256, stream, other_list, prob, xcounts, ws, dc);
   }
   if (n_lds > 0) {
@@ -266,11 +268,12 @@ int mprg_kmeans_fit(const int64_t *prob, const int32_t *kinfo, const int32_t *fi
 
 static int d_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
                               const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
-                              int32_t *km_status, int threads, void *stream) {
+                              int32_t *km_status, int threads, const uint8_t *xbytes, void *stream) {
   if (n_fits <= 0) return 0;
   if (n_init < 1 || n_init > KM_RMAX) return fail("n_init must be 1..16");
   if (threads > 64)
-    LAUNCH(k_kmeans_restart_wide, (long long)n_fits * n_init, threads, stream, prob, kinfo, fit_list, n_init, uniforms_dev, xcounts, ws, km_status);
+    LAUNCH(k_kmeans_restart_wide, (long long)n_fits * n_init, threads, stream, prob, kinfo, fit_list, n_init, uniforms_dev, xcounts, ws, km_status,
+           xbytes);
   else
     hipLaunchKernelGGL(k_kmeans_restart_one, dim3((unsigned)((long long)n_fits * n_init)), dim3(64), 0, (hipStream_t)stream, prob, kinfo, fit_list,
                        n_init, uniforms_dev, xcounts, ws, km_status);
@@ -281,12 +284,13 @@ static int d_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const i
 int mprg_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
                           const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
                           int32_t *km_status, void *stream) {
-  return d_kmeans_fit_split(prob, kinfo, fit_list, n_fits, n_init, uniforms_dev, xcounts, ws, labels, km_info, km_status, 64, stream);
+  return d_kmeans_fit_split(prob, kinfo, fit_list, n_fits, n_init, uniforms_dev, xcounts, ws, labels, km_info, km_status, 64, nullptr, stream);
 }
 int mprg_kmeans_fit_wide(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
                          const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
-                         int32_t *km_status, void *stream) {
-  return d_kmeans_fit_split(prob, kinfo, fit_list, n_fits, n_init, uniforms_dev, xcounts, ws, labels, km_info, km_status, g_km_wide_threads, stream);
+                         int32_t *km_status, const uint8_t *xbytes, void *stream) {
+  return d_kmeans_fit_split(prob, kinfo, fit_list, n_fits, n_init, uniforms_dev, xcounts, ws, labels, km_info, km_status, g_km_wide_threads, xbytes,
+                            stream);
 }
 
 int mprg_kmeans_wave_class(int64_t D, int64_t V, int k) { return (k < 2 || k > KM_KMAX) ? -1 : km_wave_class_host(D, V, k); }

@@ -70,7 +70,7 @@ KM_SPLIT_BELOW = int(os.environ.get("MPRG_KM_SPLIT_BELOW", "0"))
 # take a wide workgroup per RESTART (mprg_kmeans_fit_wide) — every phase of such a fit is thousands of chains as long as the k-mer
 # dictionary, ten restarts side by side in one workgroup queue behind one CU (profiles/r04/deep_alignment.md); 0 = never
 KM_BIG_BYTES = int(os.environ.get("MPRG_KM_BIG_BYTES", str(1 << 20)))
-# ... and from this size on the level's big problems are prepared WITHOUT the sample-sample tables of the seeding (mprg_kmeans_prepare_stats:
+# ... and from this size on the level's big problems are prepared WITHOUT the sample-sample tables of the seeding (mprg_kmeans_prepare_big, with_tables = 0:
 # 2.5 D^2 chains per problem); the wide fits then compute the few dozen rows they ask for themselves
 KM_NO_TABLES_BYTES = int(os.environ.get("MPRG_KM_NO_TABLES_BYTES", str(160 << 20)))
 # the clustering loop: "fused" = a problem's workgroup walks k = 2..10 itself (mprg_cluster_loop; one launch per workgroup form and
@@ -522,6 +522,7 @@ class ForestEngine(BatchEngine):
                     be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_x), be.stream)
         # mprg_kmeans_prepare, one launch per class of LDS need (every workgroup of a launch allocates the launch's lds_bytes)
         prep_work = 8.0 * x_doubles
+        d_xb = None
         for c in range(PREPARE_CLASSES + 1):
             n_c = int(h[2 + c])
             if not n_c:
@@ -530,8 +531,10 @@ class ForestEngine(BatchEngine):
             if c < PREPARE_CLASSES:
                 be.call("mprg_kmeans_prepare", be.ptr(d_ptab), n_c, be.ptr(d_x), be.ptr(d_ws), lst, n_c, int(h[16 + c]), 0, 0, be.stream,
                         work=prep_work)
-            elif big_level and int(h[16 + PREPARE_CLASSES]) >= KM_NO_TABLES_BYTES:          # (their fits take mprg_kmeans_fit_wide below)
-                be.call("mprg_kmeans_prepare_stats", be.ptr(d_ptab), be.ptr(d_x), be.ptr(d_ws), lst, n_c, be.stream, work=prep_work)
+            elif big_level:          # (their fits take mprg_kmeans_fit_wide below: the byte matrix; no seeding tables beyond KM_NO_TABLES_BYTES)
+                d_xb = be.empty(8 * x_doubles)
+                be.call("mprg_kmeans_prepare_big", be.ptr(d_ptab), be.ptr(d_x), be.ptr(d_ws), lst, n_c, be.ptr(d_xb),
+                        0 if int(h[16 + PREPARE_CLASSES]) >= KM_NO_TABLES_BYTES else 1, be.stream, work=prep_work)
             else:
                 be.call("mprg_kmeans_prepare", be.ptr(d_ptab), n_c, be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, lst, n_c, be.stream, work=prep_work)
             prep_work = 0.0
@@ -569,7 +572,7 @@ class ForestEngine(BatchEngine):
             self.counters["launches"] += 2 if small else 1
         else:
             self._kloop_rounds(P, d_sub, d_ptab, d_kinfo, d_x, d_ws, d_labels, d_assign, d_info, d_st, d_wc, n_wc, d_wr, n_wr, d_scratch,
-                               d_further, dd, km_events, cf_events, wide=big)
+                               d_further, dd, km_events, cf_events, wide=big, d_xb=d_xb)
         # ---- S7: MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
         self._scratch(P)
         h = self._step("splits_count", n_hdr=HDR)
@@ -610,7 +613,7 @@ class ForestEngine(BatchEngine):
 
 
     def _kloop_rounds(self, P, d_sub, d_ptab, d_kinfo, d_x, d_ws, d_labels, d_assign, d_info, d_st, d_wc, n_wc, d_wr, n_wr, d_scratch,
-                      d_further, dd, km_events, cf_events, wide=False):
+                      d_further, dd, km_events, cf_events, wide=False, d_xb=None):
         """The clustering loop as one set of launches per round k (rounds 1-3's shape; MPRG_KLOOP=rounds): the control step settles
         the previous round on the device (k_kl_advance), a retired problem's workgroups return at once."""
         be = self.be
@@ -636,8 +639,13 @@ class ForestEngine(BatchEngine):
                 stream = be.side_ptr(q) if n_side else be.stream
                 outs = out_args[:-1] + (stream,)
                 if (wide and cls is None) or n_c <= KM_SPLIT_BELOW:          # (wide: a level with BIG problems, its general-form fits)
-                    entry = "mprg_kmeans_fit_wide" if (wide and cls is None) else "mprg_kmeans_fit_split"
-                    be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, *outs, side=q if n_side else None)
+                    if wide and cls is None:          # (d_xb: the byte matrix mprg_kmeans_prepare_big wrote for the level's big problems)
+                        entry = "mprg_kmeans_fit_wide"
+                        be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, *outs[:-1], be.ptr(d_xb) if d_xb is not None else 0,
+                                outs[-1], side=q if n_side else None)
+                    else:
+                        entry = "mprg_kmeans_fit_split"
+                        be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, *outs, side=q if n_side else None)
                 elif cls is None:
                     be.call(entry, be.ptr(d_ptab), be.ptr(d_kinfo), lst, n_c, N_INIT, *fit_args, 0, 0, 0, 0, *outs, side=q if n_side else None)
                 else:

@@ -40,8 +40,11 @@ def run_kmeans_fits(be, fits, n_init=10, path="global", n_slots=3):
         in_lds = (need <= 64 * 1024) & (np.arange(P) % 5 != 4)          # every fifth problem: the global-memory form
         i_l, i_o = np.nonzero(in_lds)[0].astype(np.int32), np.nonzero(~in_lds)[0].astype(np.int32)
         d_il, d_io = be.upload(i_l), be.upload(i_o)
-        if path == "wide-stats":          # no sample-sample tables: the wide fits compute the elements their seeding asks for
-            be.call("mprg_kmeans_prepare_stats", be.ptr(d_p), be.ptr(d_x), be.ptr(d_ws), None, P, be.stream)
+        d_xb = None
+        if path in ("wide-stats", "wide-bytes"):          # K6 for big problems: the counts as bytes for the wide fits; wide-stats: no
+            d_xb = be.empty(8 * xo)                       # sample-sample tables either (the wide fits compute what their seeding asks for)
+            be.call("mprg_kmeans_prepare_big", be.ptr(d_p), be.ptr(d_x), be.ptr(d_ws), None, P, be.ptr(d_xb), 0 if path == "wide-stats" else 1,
+                    be.stream)
         else:
             be.call("mprg_kmeans_prepare", be.ptr(d_p), P, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_il), len(i_l),
                     int(need[in_lds].max()) if len(i_l) else 0, be.ptr(d_io), len(i_o), be.stream)
@@ -52,10 +55,14 @@ def run_kmeans_fits(be, fits, n_init=10, path="global", n_slots=3):
             d_slots = be.empty(8 * stride * n_slots)
             be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), None, P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws),
                     be.ptr(d_slots), stride, n_slots, be.ptr(be.empty(16)), be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
-        elif path in ("split", "wide", "wide-stats"):          # a workgroup per restart (64 / 1 024 threads), then the selection over the list
+        elif path in ("split", "wide", "wide-stats", "wide-bytes"):          # a workgroup per restart (64 / 1 024 threads), then the selection
             d_l = be.upload(np.arange(P, dtype=np.int32))
-            be.call("mprg_kmeans_fit_split" if path == "split" else "mprg_kmeans_fit_wide", be.ptr(d_p), be.ptr(d_ki), be.ptr(d_l), P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws),
-                    be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
+            if path == "split":
+                be.call("mprg_kmeans_fit_split", be.ptr(d_p), be.ptr(d_ki), be.ptr(d_l), P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws),
+                        be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
+            else:
+                be.call("mprg_kmeans_fit_wide", be.ptr(d_p), be.ptr(d_ki), be.ptr(d_l), P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws),
+                        be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.ptr(d_xb) if d_xb is not None else None, be.stream)
         elif path == "one-launch":
             be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), None, P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, 0,
                     be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)

@@ -40,9 +40,9 @@ def test_relocation_matches_oracle_persistent_workgroups():
     check(EmuBackend(), fits, path="fit", n_slots=2)              # many fits per workgroup, one scratch slot each
     check(EmuBackend(), fits, path="split")                       # a workgroup per restart, then the selection
     check(EmuBackend(), fits[:12], path="wide")                   # the same with 1 024 threads per restart (big fits)
-    # ... and with the counts read as bytes from the workspace (what a big fit's wide workgroups do: test-only build whose pool holds none)
-    check(EmuBackend(defines=("MPRG_TEST_WIDE_GLOBAL",), tag="_wideglobal"), fits[:12], path="wide")
-    # ... and without the sample-sample tables of the seeding (mprg_kmeans_prepare_stats): their elements on demand, from bytes and doubles
+    # ... and with the counts read as bytes from the caller's byte matrix (what a big fit's wide workgroups do: test-only build whose pool holds none)
+    check(EmuBackend(defines=("MPRG_TEST_WIDE_GLOBAL",), tag="_wideglobal"), fits[:12], path="wide-bytes")
+    # ... and without the sample-sample tables of the seeding (mprg_kmeans_prepare_big, with_tables = 0): their elements on demand, from bytes and doubles
     check(EmuBackend(defines=("MPRG_TEST_WIDE_GLOBAL",), tag="_wideglobal"), fits[12:24], path="wide-stats")
     check(EmuBackend(), fits[24:32], path="wide-stats")
     check(EmuBackend(), fits, path="fit", n_slots=512)

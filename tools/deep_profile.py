@@ -48,7 +48,8 @@ for p in range(passes):
     prg = eng.assemble_prgs(as_bytes=True)[0]
     be.synchronize()
     t2 = time.perf_counter()
-    rec = dict(forest_ms=round(1e3 * (t1 - t0), 2), assemble_ms=round(1e3 * (t2 - t1), 2), wall_ms=round(1e3 * (t2 - t0), 2), nodes=int(eng.n_nodes),
+    import hashlib
+    rec = dict(prg_sha256=hashlib.sha256(bytes(prg)).hexdigest(), forest_ms=round(1e3 * (t1 - t0), 2), assemble_ms=round(1e3 * (t2 - t1), 2), wall_ms=round(1e3 * (t2 - t0), 2), nodes=int(eng.n_nodes),
                levels=len(eng.levels), fits=int(eng.counters["fits"]), host_waits=int(eng.counters.get("syncs", 0)), calls=int(eng.counters["launches"]),
                prg_chars=len(prg), plan_misses=int(eng.counters.get("plan_misses", 0)),
                host="per-step host" if eng.counters.get("syncs", 0) > 3 * len(eng.levels) else "enqueued from the plan")

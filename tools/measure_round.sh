@@ -13,7 +13,7 @@ lscpu | grep -E "Model name|^CPU\(s\)|Thread|Core|Socket" >> $out/host.txt
 cat $out/host.txt
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 echo "bench rc=$?"
-inproc="--workers 0 --streams 1 --batch 8192 --no-cpu-baseline --no-end-to-end --no-cli-leg --no-single-worker-leg --no-shard-projection --steps 2"   # one process generates its alignments serially: smaller batch
+inproc="--workers 0 --streams 1 --batch 8192 --no-cpu-baseline --no-end-to-end --no-cli-leg --no-single-worker-leg --no-shard-projection --no-deep-leg --steps 2"   # one process generates its alignments serially: smaller batch
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py $inproc > $out/bench_under_rocprof.json 2> $out/prof.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py $inproc > $out/pmc_fetch_bench.json 2> $out/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py $inproc > $out/pmc_write_bench.json 2> $out/pmc_write.err
@@ -25,7 +25,7 @@ cp $stats $out/rocprofv3_kernel_stats.csv
 cut -c1-600 $out/bench_default.json
 head -30 $out/rocprofv3_kernel_stats.csv | cut -c1-160
 # 5. the fused clustering loop (what a small shard runs: < 6 000 alignments per engine): kernel stats of 3 750 alignments per pass
-inproc_small="--workers 0 --streams 1 --batch 3750 --no-cpu-baseline --no-end-to-end --no-cli-leg --no-single-worker-leg --no-shard-projection --steps 4"
+inproc_small="--workers 0 --streams 1 --batch 3750 --no-cpu-baseline --no-end-to-end --no-cli-leg --no-single-worker-leg --no-shard-projection --no-deep-leg --steps 4"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_small -- python3 bench.py $inproc_small > $out/bench_under_rocprof_3750.json 2> $out/prof_small.err
 cp $(find $out/prof_small -name "*kernel_stats.csv" | head -1) $out/rocprofv3_kernel_stats_3750_fused.csv
 head -8 $out/rocprofv3_kernel_stats_3750_fused.csv | cut -c1-160
