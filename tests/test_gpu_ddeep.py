@@ -15,15 +15,20 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("fixture", ["ddeep.json", "ddeep2.json"])
-def test_deep_hierarchical_alignment_against_the_oracle_fixture(fixture):
+@pytest.mark.parametrize("fixture,no_tables_from", [("ddeep.json", None), ("ddeep2.json", None), ("ddeep.json", 1)])
+def test_deep_hierarchical_alignment_against_the_oracle_fixture(fixture, no_tables_from, monkeypatch):
     """ddeep: 2 000 x 4 000, seed 0, -N 7; ddeep2: 900 x 2 600, seed 3, -N 3 (the nesting limit cuts the recursion short: the
-    deepest candidates become multi-allele leaves).  Both fixtures were confirmed by the REAL reference (their "reference" block)."""
+    deepest candidates become multi-allele leaves).  Both fixtures were confirmed by the REAL reference (their "reference" block).
+    The levels with big clustering problems take mprg_kmeans_fit_wide (forest.KM_BIG_BYTES); the third case also leaves the seeding's
+    tables out for them (what levels of 160 MB matrices and more do by default)."""
     from make_prg_amd.backend import HipBackend
     from make_prg_amd.forest import ForestEngine
     from make_prg_amd.msa import load_alignment_text
     from make_prg_amd.utils.gfa import GFA_Output
     from make_prg_amd.utils.synthetic import synth_deep_fasta
+    import make_prg_amd.forest as forest
+    if no_tables_from is not None:          # the big levels' problems prepared WITHOUT the seeding's tables: the wide fits compute their rows
+        monkeypatch.setattr(forest, "KM_NO_TABLES_BYTES", no_tables_from)
     with open(os.path.join(HERE, "golden", fixture)) as fh:
         g = json.load(fh)
     assert g["reference"]["prg_identical"] and g["reference"]["next_node_id_identical"]

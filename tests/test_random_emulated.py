@@ -188,3 +188,26 @@ def test_levels_with_big_problems_take_the_wide_fits(emu, monkeypatch, golden_in
     glob = EmuBackend(defines=("MPRG_TEST_WIDE_GLOBAL",), tag="_wideglobal")
     pc.check_vs_oracle(glob, random_cases(52, 24), 5, 7)
     assert pc.check_integration(glob, golden_integration) >= 30
+
+
+@pytest.mark.parametrize("no_tables_from", [1, 1 << 40])
+def test_big_problem_through_the_byte_matrix(emu, monkeypatch, no_tables_from):
+    """A clustering problem whose count matrix is beyond the LDS prepare classes (150 distinct sequences x ~250 4-mers: 300 KB) in a level
+    that counts as big: mprg_kmeans_prepare_big writes the byte matrix, the wide fits stream it — with the seeding's tables
+    (no_tables_from = huge) and without (1: their elements on demand)."""
+    import numpy as np
+    import make_prg_amd.forest as F
+    monkeypatch.setattr(F, "KM_BIG_BYTES", 200_000)
+    monkeypatch.setattr(F, "KM_NO_TABLES_BYTES", no_tables_from)
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    rng = np.random.default_rng(17)
+    clades = [rng.integers(0, 4, 34) for _ in range(3)]
+    rows = []
+    for i in range(150):
+        y = clades[i % 3].copy()
+        m = rng.random(34) < 0.25
+        y[m] = rng.integers(0, 4, int(m.sum()))
+        rows.append("ACGTACGT" + np.frombuffer(b"ACGT", np.uint8)[y].tobytes().decode() + "TTGACCAT")
+    text = "".join(f">q{i}\n{r}\n" for i, r in enumerate(rows))
+    eng = pc.check_vs_oracle(emu, [text], 2, 4)
+    assert eng._big_seen and eng.counters["max_problem_bytes"] > 156 * 1024
