@@ -148,6 +148,12 @@ int mprg_kmer_dictionary(const int64_t *views, const int64_t *prob, int n_probs,
 int mprg_kmer_counts(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size, const uint8_t *ucodes,
                      const int32_t *ulen, const int32_t *seqrow, const int64_t *occ_off, const uint8_t *table,
                      double *xcounts, void *stream);
+/* mprg_kmer_dictionary with `parts` workgroups per problem (1..1024; k-mer sizes up to 16: packed keys) — four launches: clear, insert,
+ * first-appearance flags + their count per part, ids.  Same table, flags and ids.  part_counts: int32 [n_probs * parts] of scratch.
+ * For levels whose problems hold millions of k-mer occurrences (the top of one deep alignment: 2 x 10^8 through one workgroup otherwise). */
+int mprg_kmer_dictionary_parts(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size, const uint8_t *ucodes,
+                               const int32_t *ulen, const int32_t *seqrow, int64_t *occ_off, uint8_t *table, uint8_t *first_flag,
+                               int32_t *out_V, int parts, int32_t *part_counts, void *stream);
 /* the same with `parts` workgroups per problem sharing its occurrences (1..1024): for levels that hold a problem of millions of
  * k-mer occurrences (the top of one deep alignment), whose single workgroup would otherwise decide the launch's duration */
 int mprg_kmer_counts_parts(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size, const uint8_t *ucodes,

@@ -29,6 +29,7 @@ SIGNATURES = {
                        [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "mprg_ungap_dedupe": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p, c_int] + [c_void_p] * 14),
     "mprg_kmer_dictionary": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8),
+    "mprg_kmer_dictionary_parts": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_int, c_void_p, c_void_p]),
     "mprg_kmer_counts": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 7),
     "mprg_kmer_counts_parts": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int, c_void_p]),
     "mprg_kmeans_workspace_doubles": (c_int64, [c_int64, c_int64, c_int, c_int]),

@@ -175,6 +175,21 @@ int mprg_kmer_dictionary(const int64_t *views, const int64_t *prob, int n_probs,
   return check_launch("k_kmer_dictionary");
 }
 
+int mprg_kmer_dictionary_parts(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size, const uint8_t *ucodes,
+                               const int32_t *ulen, const int32_t *seqrow, int64_t *occ_off, uint8_t *table, uint8_t *first_flag,
+                               int32_t *out_V, int parts, int32_t *part_counts, void *stream) {
+  (void)ulen;
+  if (n_probs <= 0) return 0;
+  if (kmer_size < 1 || kmer_size > KMER_PACKED_MAX) return fail("mprg_kmer_dictionary_parts: k-mer sizes 1..16 (packed keys)");
+  if (parts < 1 || parts > 1024 || !part_counts) return fail("mprg_kmer_dictionary_parts: parts must be 1..1024, part_counts given");
+  LAUNCH2(k_kmer_dict_clear, n_probs, parts, 256, stream, views, prob, ucodes, seqrow, (const int64_t *)occ_off, table);
+  LAUNCH2(k_kmer_dict_insert, n_probs, parts, 256, stream, views, prob, kmer_size, ucodes, seqrow, (const int64_t *)occ_off, table);
+  LAUNCH2(k_kmer_dict_ids, n_probs, parts, 256, stream, views, prob, kmer_size, ucodes, seqrow, (const int64_t *)occ_off, table, first_flag,
+          part_counts, out_V, 0);
+  LAUNCH2(k_kmer_dict_ids, n_probs, parts, 256, stream, views, prob, kmer_size, ucodes, seqrow, (const int64_t *)occ_off, table, first_flag,
+          part_counts, out_V, 1);
+  return check_launch("k_kmer_dict_ids");
+}
 int mprg_kmer_counts_parts(const int64_t *views, const int64_t *prob, int n_probs, int kmer_size, const uint8_t *ucodes,
                            const int32_t *ulen, const int32_t *seqrow, const int64_t *occ_off, const uint8_t *table,
                            double *xcounts, int parts, void *stream) {

@@ -73,6 +73,9 @@ KM_BIG_BYTES = int(os.environ.get("MPRG_KM_BIG_BYTES", str(1 << 20)))
 # ... and from this size on the level's big problems are prepared WITHOUT the sample-sample tables of the seeding (mprg_kmeans_prepare_big, with_tables = 0:
 # 2.5 D^2 chains per problem); the wide fits then compute the few dozen rows they ask for themselves
 KM_NO_TABLES_BYTES = int(os.environ.get("MPRG_KM_NO_TABLES_BYTES", str(160 << 20)))
+# k-mer dictionaries by KD_PARTS workgroups per problem when a level's problems hold this many k-mer occurrences on average (0 = never)
+KD_PARTS_FROM = int(os.environ.get("MPRG_KD_PARTS_FROM", str(1 << 17)))
+KD_PARTS = 128
 # the clustering loop: "fused" = a problem's workgroup walks k = 2..10 itself (mprg_cluster_loop; one launch per workgroup form and
 # level), "rounds" = one set of launches per round k (the shape of rounds 1-3)
 # "auto" (default): fused below KLOOP_ROUNDS_FROM alignments in the engine, rounds from there on.  Measured on MI355X (profiles/r04/
@@ -493,8 +496,15 @@ class ForestEngine(BatchEngine):
         d_ptab0, d_table, d_flag, d_V = be.empty(8 * PF * P), be.empty(table_bytes), be.empty(flag_bytes), be.empty(4 * P)
         self._set(PTAB0=d_ptab0, DV=d_V, P=P)
         self._step("problems_fill")
-        be.call("mprg_kmer_dictionary", be.ptr(d_sub), be.ptr(d_ptab0), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
-                be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), be.stream)
+        if KD_PARTS_FROM and K <= 16 and flag_bytes >= KD_PARTS_FROM * P:
+            # problems of (on average) this many k-mer occurrences: many workgroups per problem (the top of one deep alignment holds
+            # 2 x 10^8 occurrences in ONE problem)
+            d_pc = be.empty(4 * P * KD_PARTS)
+            be.call("mprg_kmer_dictionary_parts", be.ptr(d_sub), be.ptr(d_ptab0), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
+                    be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), KD_PARTS, be.ptr(d_pc), be.stream)
+        else:
+            be.call("mprg_kmer_dictionary", be.ptr(d_sub), be.ptr(d_ptab0), P, K, be.ptr(dd["ucodes"]), be.ptr(dd["ulen"]),
+                    be.ptr(dd["seqrow"]), be.ptr(dd["occ_off"]), be.ptr(d_table), be.ptr(d_flag), be.ptr(d_V), be.stream)
         # ---- S5: count matrices, workspaces, launch classes, biggest fits first
         self._scratch(P)
         h = self._step("sizes_count", n_hdr=21)
