@@ -221,7 +221,7 @@ int mprg_kmeans_prepare_big(const int64_t *prob, const double *xcounts, double *
                             int with_tables, void *stream) {
   if (n_list <= 0) return 0;
   LAUNCH(k_kmeans_prepare, n_list, 256, stream, list, prob, xcounts, ws, with_tables ? 0 : 1, xbytes, DS_HOST);
-  if (with_tables) LAUNCH(k_kmeans_prepare_tables, (long long)n_list * KP_PARTS, 256, stream, list, prob, xcounts, ws, DS_HOST);
+  if (with_tables) LAUNCH(k_kmeans_prepare_tables, (long long)n_list * KP_PARTS, 256, stream, list, prob, xcounts, ws, xbytes, DS_HOST);
   return check_launch("k_kmeans_prepare");
 }
 // dc: device count of the ONE list the call holds (device-counted calls pass either lds_list or other_list)
@@ -233,7 +233,7 @@ static int d_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcou
   if (n_lds > 0 && (lds_bytes <= 0 || lds_bytes > MPRG_KMEANS_PREPARE_LDS_MAX)) return fail("mprg_kmeans_prepare: lds_bytes out of range");
   if (n_other > 0) {
     LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws, 0, (uint8_t *)nullptr, dc);
-    LAUNCH(k_kmeans_prepare_tables, (long long)n_other * KP_PARTS, 256, stream, other_list, prob, xcounts, ws, dc);
+    LAUNCH(k_kmeans_prepare_tables, (long long)n_other * KP_PARTS, 256, stream, other_list, prob, xcounts, ws, (uint8_t *)nullptr, dc);
   }
   if (n_lds > 0) {
     if (lds_bytes > 64 * 1024) {     // beyond the default per-workgroup limit: gfx950 has 160 KB of LDS per CU, one such workgroup fits
