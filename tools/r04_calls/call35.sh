@@ -7,8 +7,8 @@ from make_prg_amd.utils.synthetic import synth_deep_fasta
 g = json.load(open('tests/golden/ddeep.json'))
 open('/tmp/deepcli/in/ddeep.fa', 'w').write(synth_deep_fasta(g['seed'], g['S'], g['C']))
 PY
-/usr/bin/time -v python -m make_prg_amd from_msa -i /tmp/deepcli/in -o /tmp/deepcli/out/deep -N 7 -L 7 -t 4 -O a --log /tmp/deepcli/log.txt 2> $out/time.txt; echo rc=$?
-grep -E "Elapsed|Maximum resident" $out/time.txt
+mkdir -p /tmp/deepcli/out; ( time python -m make_prg_amd from_msa -i /tmp/deepcli/in -o /tmp/deepcli/out/deep -N 7 -L 7 -t 4 -O a --log /tmp/deepcli/log.txt ) 2> $out/time.txt; echo rc=$?
+tail -5 $out/time.txt
 ls -la /tmp/deepcli/out | tee $out/ls.txt
 python - <<'PY' | tee gpurun_out/r04_c35/check.txt
 import hashlib, json
