@@ -49,6 +49,18 @@ typedef hipStream_t mprg_stream_t;
 #define ATOMIC_CAS(p, c, v) atomicCAS(p, c, v)
 #define FMA(a, b, c) __fma_rn(a, b, c)
 
+// the value lane `src` of the wavefront holds (src wave-uniform), in every lane: two v_readlane — no trip through the LDS crossbar
+// (__shfl is ds_bpermute), which matters where a wavefront folds 64 values one after the other
+#if defined(__HIP_DEVICE_COMPILE__)
+MPRG_DEV double wave_bcast(double v, int src) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#else
+MPRG_DEV double wave_bcast(double v, int src) { return __shfl(v, src); }
+#endif
+
 // ---- 64-lane wavefront idioms
 #define WAVE 64
 MPRG_DEV int wave_lane() { return (int)(threadIdx.x & (WAVE - 1)); }
