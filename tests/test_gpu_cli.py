@@ -107,3 +107,25 @@ def test_two_ranks_on_the_gpu_write_the_single_rank_files(tmp_path):
     for n in names:
         assert (tmp_path / "one" / n).read_bytes() == (tmp_path / "two" / n).read_bytes(), n
     assert (tmp_path / "one" / "pan.prg.fa").read_text().count(">") >= 39
+
+
+def test_command_line_on_one_deep_alignment(tmp_path):
+    """The command line on the FASTA file of the parity-checked deep alignment (tests/golden/ddeep.json: 2 000 x 4 000, -N 7; the real
+    reference's PRG): levels with big clustering problems take the multi-workgroup forms; every output type is written."""
+    import hashlib
+    import json
+    from make_prg_amd.utils.synthetic import synth_deep_fasta
+    with open(os.path.join(ROOT, "tests", "golden", "ddeep.json")) as fh:
+        g = json.load(fh)
+    d = tmp_path / "msas"
+    d.mkdir()
+    (d / "ddeep.fa").write_text(synth_deep_fasta(g["seed"], g["S"], g["C"]))
+    prefix = tmp_path / "out" / "deep"
+    res = subprocess.run([sys.executable, "-m", "make_prg_amd", "from_msa", "-i", str(d), "-o", str(prefix), "-N", str(g["N"]), "-L", str(g["L"]),
+                          "-t", "2", "-O", "a"], cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = (tmp_path / "out" / "deep.prg.fa").read_text().splitlines()
+    assert len(lines) == 2 and len(lines[1]) == g["expect"]["prg_len"]
+    assert hashlib.sha256(lines[1].encode()).hexdigest() == g["expect"]["prg_sha256"]
+    for suffix in (".prg.bin", ".prg.gfa", ".update_DS.zip"):
+        assert (tmp_path / "out" / ("deep" + suffix)).stat().st_size > 0
