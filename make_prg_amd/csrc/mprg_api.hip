@@ -293,7 +293,8 @@ static int d_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const i
     hipLaunchKernelGGL(k_kmeans_restart_one, dim3((unsigned)((long long)n_fits * n_init)), dim3(64), 0, (hipStream_t)stream, prob, kinfo, fit_list,
                        n_init, uniforms_dev, xcounts, ws, km_status);
   if (check_launch("k_kmeans_restart_one") != 0) return -2;
-  LAUNCH(k_kmeans_select_list, n_fits, 256, stream, prob, kinfo, fit_list, n_init, xcounts, ws, labels, km_info);
+  // (the selection predicts the labels — D x k chains as long as the k-mer dictionary: a big fit's takes the wide workgroup and the bytes too)
+  LAUNCH(k_kmeans_select_list, n_fits, threads > 64 ? threads : 256, stream, prob, kinfo, fit_list, n_init, xcounts, ws, labels, km_info, xbytes);
   return check_launch("k_kmeans_select_list");
 }
 int mprg_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int n_init,
