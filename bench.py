@@ -132,7 +132,7 @@ def source_digest():
     return h.hexdigest()[:16]
 
 
-def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None, backend_kind=None):
+def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None, backend_kind=None, first_pass=False):
     """One host worker process: owns `n_streams` engines (HIP streams, one host thread each) on GPU `device` and a share
     of the rank's alignments.  The reference's own parallelism is a process pool over MSAs (from_msa `-t`); here the
     processes feed one GPU so that the array-at-a-time host control of several sub-batches overlaps."""
@@ -158,6 +158,25 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None, backend_k
             b.synchronize()
         t_ing = time.perf_counter() - t_ing
         last = [None] * n_streams
+        # --first-pass: every pass of the timed region builds its sub-batch as a batch seen for the FIRST time — what a rank of a
+        # multi-GPU run or a chunk of the command line is: no totals of its own to size buffers from.  The capacities of its levels
+        # are predicted from ANOTHER batch (forest.ForestEngine._caps_predicted): a calibration batch of disjoint seeds, built once,
+        # untimed (the chunk before, in a real run).
+        calib = None
+        if first_pass:
+            _, cal_msas = make_batch([2_000_000 + q for q in range(max(64, min(1024, len(msas) // max(n_streams, 1))))], gen_procs)
+            with bes[0].on_stream():
+                ce = ForestEngine(bes[0], max_nesting=5, min_match_length=7)
+                ce.load(cal_msas)
+                ce.run_forest()
+                calib = ce.plan_export()
+            bes[0].synchronize()
+            del ce, cal_msas
+
+        def enqueue(i):
+            if first_pass:
+                engs[i]._plan, engs[i].plan_donor = None, calib
+            engs[i].forest_enqueue()
 
         def collect_one(i, fin):
             prgs = fin()
@@ -176,7 +195,7 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None, backend_k
                 return 0, 0
             for i in range(n_streams):
                 with bes[i].on_stream():
-                    engs[i].forest_enqueue()
+                    enqueue(i)
             for step in range(n_steps):
                 for i in range(n_streams):
                     with bes[i].on_stream():
@@ -185,7 +204,7 @@ def _worker(conn, device, seeds, n_streams, gen_procs=1, cli_dir=None, backend_k
                         # host buffer on the copy stream; collected one step later, so the copy overlaps the next step's kernels
                         fin = engs[i].assemble_prgs(as_bytes=True, lazy=True)
                         if step + 1 < n_steps:
-                            engs[i].forest_enqueue()
+                            enqueue(i)
                     if pending[i] is not None:
                         collect_one(i, pending[i])
                     pending[i] = fin
@@ -306,6 +325,9 @@ def main():
                     help="alignments of the job per step (default: the whole 30k-gene pan-genome of BASELINE.json, ~15 GB of HBM); "
                          "sharded over the ranks unless --weak")
     ap.add_argument("--weak", action="store_true", help="every rank builds all --batch alignments (weak scaling)")
+    ap.add_argument("--first-pass", action="store_true",
+                    help="every timed pass builds its alignments as a batch seen for the first time: level capacities predicted from a "
+                         "DIFFERENT (calibration) batch instead of taken from the previous pass of the same batch")
     ap.add_argument("--no-single-worker-leg", action="store_true")
     ap.add_argument("--no-shard-projection", action="store_true", help="skip the runs at the shard sizes of 2 / 4 / 8 GPUs (N=1 only)")
     ap.add_argument("--no-cli-leg", action="store_true", help="skip the file -> file run of the command line (N=1 only)")
@@ -389,14 +411,14 @@ def main():
     conns, procs, th = [], [], None
     for w in range(W):
         a, b = ctx.Pipe()
-        pr = ctx.Process(target=_worker, args=(b, local_rank, parts[w], args.streams, gen_procs, cli_dir))
+        pr = ctx.Process(target=_worker, args=(b, local_rank, parts[w], args.streams, gen_procs, cli_dir, None, args.first_pass))
         pr.start()
         conns.append(a); procs.append(pr)
     if W == 0:          # --workers 0: the same worker loop on a thread of this process (rocprofv3 runs: nothing forks)
         import threading
         a, b = ctx.Pipe()
         # (this process also runs torch: its worker thread takes its buffers and streams from torch too — one HIP runtime per process)
-        th = threading.Thread(target=_worker, args=(b, local_rank, seeds, args.streams, 1, None, "torch"), daemon=True)
+        th = threading.Thread(target=_worker, args=(b, local_rank, seeds, args.streams, 1, None, "torch", args.first_pass), daemon=True)
         th.start()
         conns.append(a)
 
@@ -524,7 +546,8 @@ def main():
     if rank == 0 and world == 1 and W > 1 and not args.no_single_worker_leg:
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--workers", "1", "--steps", str(max(3, args.steps // 2)), "--warmup", "2",
-               "--batch", str(args.batch), "--no-cpu-baseline", "--no-end-to-end", "--no-single-worker-leg", "--no-cli-leg", "--no-deep-leg"]
+               "--batch", str(args.batch), "--no-cpu-baseline", "--no-end-to-end", "--no-single-worker-leg", "--no-cli-leg", "--no-deep-leg",
+               "--no-shard-projection"]
         try:
             line = subprocess.run(cmd, capture_output=True, text=True, timeout=900, check=True).stdout.strip().splitlines()[-1]
             one = json.loads(line)
@@ -538,23 +561,28 @@ def main():
     #      with four host workers (fresh child processes).  The driver computes scaling from its own 8-GPU runs; this is the
     #      projection a one-GPU box can make: N x shard rate / value.
     projection = None
-    if rank == 0 and world == 1 and W >= 1 and not args.no_shard_projection and not args.no_single_worker_leg:
+    if rank == 0 and world == 1 and W >= 1 and not args.no_shard_projection:
         import subprocess
         projection = dict(note="alignments per step = batch / N on ONE GPU (what a rank of an N-GPU run builds); projected speed-up = "
                                "N x shard rate / value of this line", shards=[])
         for n_gpus in (2, 4, 8):
             shard = args.batch // n_gpus
             entry = dict(n_gpus=n_gpus, alignments_per_step=shard)
-            for label, w in (("one_worker", "1"), ("default_workers", "4")):
-                cmd = [sys.executable, os.path.abspath(__file__), "--workers", w, "--steps", "6", "--warmup", "2", "--batch", str(shard),
-                       "--no-cpu-baseline", "--no-end-to-end", "--no-single-worker-leg", "--no-cli-leg", "--no-shard-projection", "--no-deep-leg"]
+            # planned: the passes after the first of a resident batch (capacities = the batch's own previous totals); first_pass: every
+            # pass sized from ANOTHER batch's totals with headroom — what a rank that sees its shard once, or a chunk of the command
+            # line, gets (--first-pass).  Host shape: this file's default for the shard's size.
+            for label, extra in (("planned", []), ("first_pass", ["--first-pass"])):
+                cmd = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--batch", str(shard),
+                       "--no-cpu-baseline", "--no-end-to-end", "--no-single-worker-leg", "--no-cli-leg", "--no-shard-projection", "--no-deep-leg"] + extra
                 try:
                     line = subprocess.run(cmd, capture_output=True, text=True, timeout=900, check=True).stdout.strip().splitlines()[-1]
                     one = json.loads(line)
                     c1 = one["config"]
                     entry[label] = dict(value=one["value"], ms_per_step=one["ms_per_step"], worker_processes=c1["host_worker_processes_per_gpu"],
                                         engines_per_worker=c1["streams_per_worker"], host_waits_per_step=c1["host_waits_per_step"],
-                                        calls_per_step=c1["launches_per_step"], verified_mismatches=c1["verified"]["mismatches"],
+                                        calls_per_step=c1["launches_per_step"], plan_misses_per_step=c1["plan_misses_per_step"],
+                                        levels_left_to_the_per_step_host_per_step=c1["plan_resumes_per_step"],
+                                        verified_mismatches=c1["verified"]["mismatches"],
                                         projected_speedup=round(n_gpus * one["value"] / value, 3))
                 except Exception as err:          # reported, not hidden
                     entry[label] = dict(error=f"{type(err).__name__}: {err}"[:300])
@@ -641,7 +669,7 @@ def main():
             deep = dict(error=f"{type(err).__name__}: {err}"[:400])
 
     # whole-job counters (strong scaling: a rank's workers only saw its shard)
-    keys = ("launches", "fits", "cells_all", "cells_clustered", "kmeans_bytes", "syncs")
+    keys = ("launches", "fits", "cells_all", "cells_clustered", "kmeans_bytes", "syncs", "plan_misses", "plan_resumes")
     cvec = torch.tensor([float(counters.get(k_, 0)) for k_ in keys], dtype=torch.float64, device=device if (dist_backend == "nccl" and world > 1) else "cpu")
     if world > 1:
         dist.all_reduce(cvec, op=dist.ReduceOp.SUM)
@@ -703,6 +731,8 @@ def main():
                        "step_includes": "recursion forest (kernels + device-side bookkeeping; the host sizes buffers from one header per "
                                         "step) + PRG text laid out and written on the device + its copy to pinned host memory",
                        "host_waits_per_step": counters.get("syncs", 0) / args.steps,
+                       "first_pass": bool(args.first_pass), "plan_misses_per_step": counters.get("plan_misses", 0) / args.steps,
+                       "plan_resumes_per_step": counters.get("plan_resumes", 0) / args.steps,
                        "ingest_s_excluded": round(t_ing, 3), "loci_built_last_step": n_ok,
                        "levels": counters["levels"] / args.steps, "launches_per_step": counters["launches"] / args.steps,
                        "kmeans_fits_per_step": counters["fits"] / args.steps,

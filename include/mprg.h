@@ -390,7 +390,9 @@ enum {
   MPRG_CAP_UBYTES = 7, MPRG_CAP_SCOLS = 8, MPRG_CAP_NDD = 9, MPRG_CAP_WC = 10, MPRG_CAP_WR = 11 /* work items of the k = 1 check */,
   MPRG_CAP_TABLE = 12, MPRG_CAP_FLAG = 13, MPRG_CAP_LO = 14, MPRG_CAP_XD = 15, MPRG_CAP_WSD = 16, MPRG_CAP_CLS = 17 /* .. 21: problems per
   mprg_kmeans_prepare class */, MPRG_CAP_LDS = 22 /* .. 25: LDS bytes each LDS class is launched with */, MPRG_CAP_NCHILD = 26,
-  MPRG_CAP_POOL = 27 /* entries of the row pool */
+  MPRG_CAP_POOL = 27 /* entries of the row pool */,
+  MPRG_CAP_BIG = 28 /* optional (0: no limit): a clustering problem whose count matrix needs more bytes than this makes the level
+                     * overflow (step MPRG_STEP_SIZES_SHAPE) — the host has wider launch forms for such problems (mprg_kmeans_fit_wide) */
 };
 /* ---- a recursion level WITHOUT a host wait.  mprg_forest_level enqueues every step of one level — S1 .. S7 below and the data entry
  * points between them (mprg_column_masks, mprg_partition, mprg_ungap_dedupe, mprg_cluster_further (k = 1), mprg_kmer_dictionary,
@@ -411,8 +413,16 @@ enum { MPRG_DS_OVERFLOW = 0 /* 0, or 100 * (level + 1) + the step whose totals d
        MPRG_DS_NNODES = 3, MPRG_DS_POOL_USED = 4, MPRG_DS_LEVEL = 5 /* levels enqueued so far */,
        MPRG_DS_NFAILED = 6 /* set when a view's partition failed (its locus is dropped: MPRG_F_FAILED, MPRG_F_ERR_FIRST) */, MPRG_DS_GLOBAL = 16,
        MPRG_DS_LEVEL_WORDS = 6 * 96 };
-enum { MPRG_STEP_FRONTIER = 0, MPRG_STEP_CLASSIFY = 1, MPRG_STEP_CLUSTER = 2, MPRG_STEP_PROBLEMS = 3, MPRG_STEP_SIZES = 4, MPRG_STEP_SPLITS = 5 };
+enum { MPRG_STEP_FRONTIER = 0, MPRG_STEP_CLASSIFY = 1, MPRG_STEP_CLUSTER = 2, MPRG_STEP_PROBLEMS = 3, MPRG_STEP_SIZES = 4, MPRG_STEP_SPLITS = 5,
+       /* overflow codes only: */ MPRG_STEP_SIZES_SHAPE = 7 /* an LDS class's launch size, or MPRG_CAP_BIG */, MPRG_STEP_BEGIN = 9 /* the frontier itself */ };
 int mprg_forest_level(const int64_t *F, void *stream);
+/* A level whose totals did not fit need not cost the forest: k_ds_begin keeps, in words 15-17 of every level's frontier block, what
+ * the forest's state was when the level began (frontier size, node-table rows, row-pool entries).  mprg_forest_state_rewind puts the
+ * device state back to the start of `level` and clears MPRG_DS_OVERFLOW; the host then enqueues that level and the ones after it
+ * again with larger buffers (mprg_forest_level, same MPRG_F_LEVEL_INDEX) — the levels before it stand.  Safe because a level's kernels
+ * return at once from the overflow on and its only write that a second run would read differently (the nesting level of a new
+ * MultiClusterNode, k_sp_children) comes after the level's last capacity check. */
+int mprg_forest_state_rewind(int64_t *ds, long long level, void *stream);
 /* zeroes the device state (n_words int64) and sets the forest's roots: ds[MPRG_DS_N] = ds[MPRG_DS_NNODES] = n_roots */
 int mprg_forest_state_init(int64_t *ds, long long n_words, long long n_roots, void *stream);
 /* S1  frontier -> views.  hdr: 0 views, 1 their columns, 2 their rows, 3 fused views, 4 other views, 5-9 mask work items for

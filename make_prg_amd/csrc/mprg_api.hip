@@ -605,6 +605,11 @@ int mprg_forest_state_init(int64_t *ds, long long n_words, long long n_roots, vo
   LAUNCH(k_ds_init, 1, 64, stream, ds, n_roots);
   return check_launch("k_ds_init");
 }
+int mprg_forest_state_rewind(int64_t *ds, long long level, void *stream) {
+  if (!ds || level < 0) return fail("mprg_forest_state_rewind: no device state / negative level");
+  LAUNCH(k_ds_rewind, 1, 64, stream, ds, level);
+  return check_launch("k_ds_rewind");
+}
 // One recursion level, every step enqueued, nothing read back (include/mprg.h: "a recursion level WITHOUT a host wait").
 int mprg_forest_level(const int64_t *F, void *stream) {
   int64_t *ds = FP(int64_t, MPRG_F_DS);
@@ -629,7 +634,7 @@ int mprg_forest_level(const int64_t *F, void *stream) {
   const int Lm = (int)F[MPRG_F_MIN_MATCH];
   // ---- S1 frontier -> views -> column masks, partition
   const long long cap_n = F[MPRG_F_N], cap_na = F[MPRG_F_N_VIEWS];
-  LAUNCH(k_ds_begin, 1, 64, stream, ds, blk(MPRG_STEP_FRONTIER), cap_n, 100 * (L + 1) + 9);
+  LAUNCH(k_ds_begin, 1, 64, stream, ds, blk(MPRG_STEP_FRONTIER), cap_n, 100 * (L + 1) + MPRG_STEP_BEGIN);
   if (cap_n <= 0) {                              // the plan ends here: a frontier that is not empty is an overflow (k_ds_begin)
     LAUNCH(k_ds_advance, 1, 64, stream, ds, (const int64_t *)blk(MPRG_STEP_CLASSIFY), (const int64_t *)blk(MPRG_STEP_SPLITS));
     return check_launch("k_ds_advance");
@@ -705,7 +710,15 @@ int mprg_forest_level(const int64_t *F, void *stream) {
         if (kf_sizes_count(F, st4, b3 + 0, stream) != 0) return -1;
         check(MPRG_STEP_SIZES, 7, {C[MPRG_CAP_XD], C[MPRG_CAP_WSD], C[MPRG_CAP_CLS], C[MPRG_CAP_CLS + 1], C[MPRG_CAP_CLS + 2], C[MPRG_CAP_CLS + 3],
                                    C[MPRG_CAP_CLS + 4]});
-        check(MPRG_STEP_SIZES, 4, {C[MPRG_CAP_LDS], C[MPRG_CAP_LDS + 1], C[MPRG_CAP_LDS + 2], C[MPRG_CAP_LDS + 3]}, -1, 0, 0, -1, 0, 0, b4 + 16);
+        // (b4[16 + c]: the largest LDS need of class c; class 4 = the global form, whose "need" is the size of the problem's count matrix:
+        //  MPRG_CAP_BIG leaves a level that holds a BIG problem to the host, which has wider kernels for it; code: step 7)
+        {
+          DsCaps lcaps;
+          for (int q = 0; q < 16; ++q) lcaps.cap[q] = BIG;
+          for (int q = 0; q < 4; ++q) lcaps.cap[q] = C[MPRG_CAP_LDS + q];
+          if (C[MPRG_CAP_BIG] > 0) for (int q = 0; q < 5; ++q) if (lcaps.cap[q] > C[MPRG_CAP_BIG]) lcaps.cap[q] = C[MPRG_CAP_BIG];
+          LAUNCH(k_ds_check, 1, 64, stream, ds, (const int64_t *)(b4 + 16), 5, lcaps, 100 * (L + 1) + MPRG_STEP_SIZES_SHAPE, -1, 0, 0LL, -1, 0, 0LL);
+        }
         if (kf_sizes_fill(F, st4, b3 + 0, stream) != 0) return -1;
         LAUNCH(k_kmer_counts, cap_p, 512, stream, FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_PTAB), Lm, FP(const uint8_t, MPRG_F_UCODES),
                FP(const int32_t, MPRG_F_SEQROW), FP(const int64_t, MPRG_F_OCC_OFF), FP(const uint8_t, MPRG_F_TABLE), FP(double, MPRG_F_X), dp);
@@ -730,8 +743,9 @@ int mprg_forest_level(const int64_t *F, void *stream) {
           if (split) {
             if (hipEventCreateWithFlags(&e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e_join, hipEventDisableTiming) != hipSuccess)
               return fail("event");
-            hipEventRecord(e_fork, (hipStream_t)stream);
-            hipStreamWaitEvent((hipStream_t)side, e_fork, 0);
+            // (a wait that silently failed would let the side stream's launches race the level's tables)
+            if (hipEventRecord(e_fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)side, e_fork, 0) != hipSuccess)
+              return fail("mprg_forest_level: fork onto the side stream");
           }
           auto loop = [&](int which, void *on) {
             return d_cluster_loop(FP(const int64_t, MPRG_F_SUB), FP(const int64_t, MPRG_F_PTAB), (int)cap_p, (int)F[MPRG_F_N_INIT], FP(const double, MPRG_F_UNIFORMS),
@@ -743,9 +757,10 @@ int mprg_forest_level(const int64_t *F, void *stream) {
           if (split) {
             if (loop(forms & (MPRG_LOOP_GENERAL | MPRG_LOOP_SKIP_SMALL), stream) != 0) return -1;
             if (loop(forms & (MPRG_LOOP_SMALL_LOW | MPRG_LOOP_SMALL_HIGH), side) != 0) return -1;
-            hipEventRecord(e_join, (hipStream_t)side);
-            hipStreamWaitEvent((hipStream_t)stream, e_join, 0);
-            hipEventDestroy(e_fork); hipEventDestroy(e_join);          // (released by the runtime once the recorded work is done)
+            if (hipEventRecord(e_join, (hipStream_t)side) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, e_join, 0) != hipSuccess)
+              return fail("mprg_forest_level: join of the side stream");
+            // (released by the runtime once the recorded work is done)
+            if (hipEventDestroy(e_fork) != hipSuccess || hipEventDestroy(e_join) != hipSuccess) return fail("mprg_forest_level: event release");
           } else if (loop(forms, stream) != 0) return -1;
         }
         // ---- S7 MultiClusterNodes and their children

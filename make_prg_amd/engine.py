@@ -92,7 +92,7 @@ class BatchEngine:
         self._uniform_cache: Dict[int, object] = {}
         self.timers: Dict[str, float] = {}
         self.counters: Dict[str, float] = dict(cells_all=0, cells_clustered=0, kmeans_bytes=0, fits=0, levels=0,
-                                               launches=0, syncs=0)
+                                               launches=0, syncs=0, plan_misses=0, plan_resumes=0)
 
     # ------------------------------------------------------------------------------------------------ packing
     def _resolve_pending_n(self, msas: List[MSA]):

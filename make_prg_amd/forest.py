@@ -47,7 +47,8 @@ for _i, _n in enumerate("DS LEVEL_INDEX MASK MAXRUN STACK IVFLAG IV NIV STATUS I
     FI[_n] = 96 + _i
 (CAP_TCOLS, CAP_NFUSED, CAP_NOTHER, CAP_ITEMS, CAP_NGAP, CAP_NODES, CAP_SROWS, CAP_UBYTES, CAP_SCOLS, CAP_NDD, CAP_WC, CAP_WR, CAP_TABLE, CAP_FLAG,
  CAP_LO, CAP_XD, CAP_WSD) = range(17)
-CAP_CLS, CAP_LDS, CAP_NCHILD, CAP_POOL = 17, 22, 26, 27
+CAP_CLS, CAP_LDS, CAP_NCHILD, CAP_POOL, CAP_BIG = 17, 22, 26, 27, 28
+STEP_SIZES_SHAPE, STEP_BEGIN = 7, 9          # overflow codes beside the six steps (MPRG_STEP_*)
 FI["SIDE_STREAM"] = 160
 FI["MAX_ROWS"] = 161
 DS_OVERFLOW, DS_F0, DS_N, DS_NNODES, DS_POOL_USED, DS_LEVEL, DS_NFAILED, DS_GLOBAL, DS_LEVEL_WORDS = 0, 1, 2, 3, 4, 5, 6, 16, 6 * 96
@@ -87,6 +88,23 @@ KLOOP_ROUNDS_FROM = int(os.environ.get("MPRG_KLOOP_ROUNDS_FROM", "6000"))
 LOOP_GENERAL, LOOP_SMALL = "mprg_cluster_loop[general]", "mprg_cluster_loop[small]"          # names the fused launches are timed under
 F_FIELDS = 192
 PREPARE_CLASSES = 4                      # LDS classes of mprg_kmeans_prepare (+ the global-memory form)
+PREPARE_LDS_BOUNDS = (12 * 1024, 24 * 1024, 64 * 1024, 156 * 1024)          # kf_prepare_class (csrc/k_forest.inc), MPRG_KMEANS_PREPARE_LDS_MAX
+# ---- capacities of a FIRST-SEEN batch (ForestEngine._caps_predicted): which total of a level — (step, column) of its headers — is a sum
+# over which count; [0][14] (the frontier) follows from the level before
+_CAP_COLS = {(0, 0): (0, 14), (0, 1): (0, 0), (0, 3): (0, 14), (0, 4): (0, 14), (0, 5): (0, 4), (0, 6): (0, 4), (0, 7): (0, 4), (0, 8): (0, 4),
+             (0, 9): (0, 4), (0, 10): (0, 4),
+             (1, 0): (0, 0), (1, 1): (0, 0), (1, 2): (1, 1), (1, 3): (1, 1), (1, 4): (1, 1), (1, 5): (1, 1),
+             (2, 0): (1, 1), (2, 1): (2, 0), (2, 2): (2, 0),
+             (3, 0): (2, 0), (3, 1): (3, 0), (3, 2): (3, 0), (3, 3): (3, 0),
+             (4, 0): (3, 0), (4, 1): (3, 0), (4, 2): (3, 0), (4, 3): (3, 0), (4, 4): (3, 0), (4, 5): (3, 0), (4, 6): (3, 0),
+             (5, 0): (3, 0), (5, 1): (5, 0), (5, 2): (5, 0)}
+PLAN_HEAD = float(os.environ.get("MPRG_PLAN_HEAD", "1.35"))          # headroom of a predicted total ...
+PLAN_SPREAD = float(os.environ.get("MPRG_PLAN_SPREAD", "24"))        # ... + this / sqrt(items behind it)
+PLAN_FLOOR = float(os.environ.get("MPRG_PLAN_FLOOR", "8"))           # room for this many more items of the donor's largest average size
+DONOR_MIN_ROOTS = int(os.environ.get("MPRG_DONOR_MIN_ROOTS", "16"))  # a forest of fewer alignments is nobody's donor
+DONOR_MAX_RATIO = 32.0
+SPEC_RETRIES = int(os.environ.get("MPRG_SPEC_RETRIES", "6"))         # levels enqueued again after an overflow before the per-step host takes over
+SPEC_SPARE_LEVELS = 4                    # room in the device state for levels beyond the capacities' (a forest deeper than its donor's)
 
 
 class ForestEngine(BatchEngine):
@@ -157,17 +175,20 @@ class ForestEngine(BatchEngine):
         one per alignment): re-entry below an existing parent (LeafNode._update_leaf, recursion_tree.py:374-376) starts at
         the parent's nesting level and does not force a MultiIntervalNode.
         Two ways through a level: the per-step host (`_forest_level`: every step's totals are read back to size the next buffers,
-        ~6 waits per level) and — when this engine has a PLAN, the totals of every step of an earlier forest of the same resident
-        batch — mprg_forest_level: buffers sized from the plan, exact counts on the device, no wait until the forest is enqueued
-        (`_forest_speculative`); a total beyond its capacity makes the device drop the rest and the host falls back to the first
-        way (and a fresh plan)."""
+        ~6 waits per level + one per KMeans round) and mprg_forest_level: the level's buffers sized from CAPACITIES, exact counts
+        on the device, no wait until the whole forest is enqueued.  Capacities come from the totals of an earlier forest of the
+        same resident batch (`_plan`: exact, no headroom) or — a batch seen for the FIRST time, what the command line's chunks
+        and a rank's shard are — from the totals of ANOTHER batch (`plan_donor`, see plan_export), scaled by the batches' cells,
+        with headroom.  A total beyond its capacity stops the device at that level; the host then enqueues that level and the
+        ones after it again with larger buffers (mprg_forest_state_rewind: the levels before it are kept), and leaves the rest
+        to the per-step host when that does not settle it or the level holds a BIG clustering problem."""
         self.forest_enqueue(root_level, root_is_tree_root)
         self.forest_finish()
 
     def forest_enqueue(self, root_level=0, root_is_tree_root=True):
-        """First half of run_forest.  With a plan: the whole forest is ENQUEUED and the call returns (no wait; several engines on
-        streams of their own can be fed by one host thread in turn); without: the per-step host runs the forest here.
-        forest_finish() completes either."""
+        """First half of run_forest.  With capacities (a plan of its own or a donor's): the whole forest is ENQUEUED and the call
+        returns (no wait; several engines on streams of their own can be fed by one host thread in turn); without: the per-step
+        host runs the forest here.  forest_finish() completes either."""
         M = len(self._msas)
         per = lambda v, dt: np.asarray(v, dt) if isinstance(v, (list, tuple, np.ndarray)) else np.full(M, v, dt)
         root_levels, forced = per(root_level, np.int64), per(root_is_tree_root, bool)
@@ -175,36 +196,56 @@ class ForestEngine(BatchEngine):
         self._forest_begin(root_levels, forced, key)
         self._roots_args = (root_levels, forced, key)
         plan = getattr(self, "_plan", None)
-        self._pending_plan = None
-        if SPECULATIVE and plan is not None and plan["key"] == key and self.be.profile is None and len(self.ok):
-            self._pending_plan = self._forest_speculative_enqueue(plan)
+        self._pending = None
+        caps = None
+        if SPECULATIVE and self.be.profile is None and len(self.ok) and self.kloop_fused:
+            if plan is not None and plan["key"] == key:
+                caps = self._caps_own(plan)
+            elif not root_levels.any() and forced.all():          # (whole alignments from their roots: what a donor's totals describe)
+                donor = getattr(self, "plan_donor", None) or getattr(self.be, "plan_donor", None)
+                caps = self._caps_predicted(donor) if donor is not None else None
+        self._whole_roots = not root_levels.any() and bool(forced.all())
+        if caps is not None:
+            self._pending = self._spec_enqueue(caps)
         else:
             self._forest_exact()
 
     def forest_finish(self):
-        """Second half of run_forest: waits for a forest that was enqueued from a plan and looks at the device state (a total that
-        did not fit: the forest is repeated by the per-step host)."""
-        done_by_plan = False
-        if self._pending_plan is not None:
-            done_by_plan = self._forest_speculative_finish(*self._pending_plan)
-            self._pending_plan = None
-            if not done_by_plan:          # a capacity was exceeded: start over, exact sizes
-                self.counters["plan_misses"] = self.counters.get("plan_misses", 0) + 1
-                self._plan = None
-                self._forest_begin(*self._roots_args)
-                self._forest_exact()
+        """Second half of run_forest: waits for a forest that was enqueued from capacities and looks at the device state (a total
+        that did not fit: see run_forest)."""
+        by_device = False
+        if self._pending is not None:
+            by_device = self._spec_finish(self._pending)
+            self._pending = None
         self._nodes_hint, self._pool_hint = self.n_nodes + (self.n_nodes >> 4), self.pool_used + (self.pool_used >> 4)
-        self._forest_end(check_failed=not done_by_plan or self._spec_failed)
+        self._forest_end(check_failed=not by_device or self._spec_failed)
+        # the next batch built on this backend — the command line's next chunk, a rank's next shard — is sized from this one
+        if self._whole_roots and len(self.ok) >= DONOR_MIN_ROOTS:
+            donor = self.plan_export()
+            if donor is not None:
+                self.be.plan_donor = donor
+
+    def plan_export(self):
+        """What another engine needs to size ITS first forest from this engine's last one (`other.plan_donor = this.plan_export()`):
+        every step's totals per level, the roots and their cells.  None when the last forest left no plan (a batch with BIG clustering
+        problems, or the per-round clustering loop)."""
+        plan = getattr(self, "_plan", None)
+        if plan is None or not len(self.ok):
+            return None
+        return dict(levels=plan["levels"], n_roots=len(self.ok), cells=float((self.meta_arr[self.ok, 4] * self.meta_arr[self.ok, 5]).sum()),
+                    settings=(self.max_nesting, self.L))
 
     def _forest_exact(self):
         """The per-step host: every step's totals read back; writes the plan the next forest of this batch is sized from."""
         self._plan_rec = []
         self._big_seen = False
-        f0, n = 0, len(self.ok)
+        self._forest_exact_levels(0, len(self.ok))
+
+    def _forest_exact_levels(self, f0: int, n: int):
         while n:
             self.counters["levels"] += 1
             f0, n = self._forest_level(f0, n)
-            self._alive = {k: v for k, v in self._alive.items() if k in ("NODES", "META", "FAILED", "ERR_FIRST", "POOL", "ARENA", "HDR", "HDR_HOST")}
+            self._alive = {k: v for k, v in self._alive.items() if k in ("NODES", "META", "FAILED", "ERR_FIRST", "POOL", "ARENA", "HDR", "HDR_HOST", "UNIFORMS")}
         # (a plan is the sizes of a forest whose clustering loops are the fused ones: none for a batch with BIG problems)
         self._plan = dict(key=self._roots_args[2], levels=self._plan_rec, n_nodes=self.n_nodes, pool_used=self.pool_used) \
             if (self.kloop_fused and not self._big_seen) else None
@@ -282,56 +323,156 @@ class ForestEngine(BatchEngine):
                                        if code == 2 else PartitioningError("Failed interval partitioning"))
 
     # ------------------------------------------------------------------------------------------------ levels without host waits
-    def _forest_speculative_enqueue(self, plan):
-        """Every level of the forest enqueued from the plan's totals (mprg_forest_level); no wait."""
+    def _caps_own(self, plan):
+        """Capacities = the totals of this batch's previous forest (no headroom: the same forest again)."""
+        return dict(levels=[{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in lv.items()} for lv in plan["levels"]],
+                    n_nodes=int(plan["n_nodes"]), pool=int(plan["pool_used"]), predicted=False)
+
+    def _caps_predicted(self, donor):
+        """Capacities of a batch seen for the first time, from the totals of ANOTHER batch: every total scaled by the ratio of the
+        batches' cells, times a headroom that grows as the number of items behind the total shrinks (a total over n items is
+        predicted to ~ 1 / sqrt(n)), plus room for PLAN_FLOOR more items of the largest average size any level of the donor saw.
+        One level more than the donor had, with the floor's room only.  The chain of frontiers is made consistent (a level's
+        frontier holds what the level before may create), the LDS classes are launched with their upper bounds."""
+        if donor.get("settings") != (self.max_nesting, self.L):
+            return None
+        ok = self.ok
+        r = float((self.meta_arr[ok, 4] * self.meta_arr[ok, 5]).sum()) / max(float(donor["cells"]), 1.0)
+        if not (1.0 / DONOR_MAX_RATIO <= r <= DONOR_MAX_RATIO):          # (a batch of another order of magnitude says little)
+            return None
+        src = donor["levels"]
+        unit = {}
+        for (st, c), (cs, cc) in _CAP_COLS.items():
+            unit[(st, c)] = max([1.0] + [float(lv[st][c]) / max(float(lv[cs][cc]), 1.0) for lv in src])
+
+        def cap_of(lv, st, c):
+            cs, cc = _CAP_COLS[(st, c)]
+            pred, n_pred = (r * float(lv[st][c]), r * float(lv[cs][cc])) if lv is not None else (0.0, 0.0)
+            return int(np.ceil(pred * (PLAN_HEAD + PLAN_SPREAD / np.sqrt(n_pred + 1.0)) + PLAN_FLOOR * unit[(st, c)]))
+
+        levels, n_front = [], len(ok)
+        n_nodes, pool = len(ok), 0
+        for lv in list(src) + [None]:
+            out = {s_: np.zeros(HDR, np.int64) for s_ in range(6)}
+            for (st, c) in _CAP_COLS:
+                out[st][c] = cap_of(lv, st, c)
+            out[0][14] = n_front
+            for c in (0, 3, 4):          # views, fused views, other views: at most the frontier
+                out[0][c] = min(int(out[0][c]), n_front)
+            items = [r * float(lv[0][5 + q]) for q in range(5)] if lv is not None else [0.0] * 5
+            out["rpc_idx"] = next((i for i in range(4) if items[i] >= 1024), 4)
+            for c in range(PREPARE_CLASSES):
+                out[4][16 + c] = PREPARE_LDS_BOUNDS[c]
+            levels.append(out)
+            n_front = int(out[1][0] + out[5][2])
+            n_nodes += n_front
+            pool += int(out[5][1])
+        return dict(levels=levels, n_nodes=n_nodes, pool=pool, predicted=True)
+
+    @staticmethod
+    def _caps_grow(caps, L: int, seen):
+        """After an overflow in level L: twice the room from that level on, and at least what the device counted there (`seen`: the
+        level's step blocks — only the steps up to the one that overflowed hold this attempt's totals, which max() keeps)."""
+        levels = caps["levels"]
+        while len(levels) <= L:          # (deeper than planned: one more level like the last)
+            levels.append({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in levels[-1].items()})
+        for li in range(L, len(levels)):
+            lv = levels[li]
+            for (st, c) in _CAP_COLS:
+                lv[st][c] = 2 * int(lv[st][c]) + 8
+            lv[0][14] = 2 * int(lv[0][14]) + 8
+            for c in range(PREPARE_CLASSES):          # (a class that was empty may now be launched: with the class's upper bound)
+                lv[4][16 + c] = PREPARE_LDS_BOUNDS[c]
+        lv = levels[L]
+        for (st, c) in _CAP_COLS:
+            lv[st][c] = max(int(lv[st][c]), int(seen[st][c]))
+        lv[0][14] = max(int(lv[0][14]), int(seen[0][15]))
+        for li in range(L + 1, len(levels)):          # a frontier holds what the level before may create
+            levels[li][0][14] = max(int(levels[li][0][14]), int(levels[li - 1][1][0] + levels[li - 1][5][2]))
+        caps["n_nodes"] = 2 * int(caps["n_nodes"]) + sum(int(lv[0][14]) for lv in levels[L:])
+        caps["pool"] = 2 * int(caps["pool"]) + sum(int(lv[5][1]) for lv in levels[L:])
+
+    def _spec_enqueue(self, caps):
+        """Every level of the forest enqueued from capacities (mprg_forest_level); no wait."""
         be = self.be
-        levels = plan["levels"]
-        nL = len(levels)
-        cap = lambda x: int(x)          # the plan is this batch's own: its totals are the capacities
-        n_words = DS_GLOBAL + (nL + 1) * DS_LEVEL_WORDS
+        n_words = DS_GLOBAL + (len(caps["levels"]) + 1 + SPEC_SPARE_LEVELS) * DS_LEVEL_WORDS
         d_ds = be.empty(8 * n_words)
         be.call("mprg_forest_state_init", be.ptr(d_ds), n_words, len(self.ok), be.stream)
-        # node table and row pool for the whole forest (no growing on the way)
-        self.cap_nodes = max(self.cap_nodes, cap(plan["n_nodes"]))
-        if 8 * NODE_FIELDS * self.cap_nodes > len(self.d_nodes):
-            self.d_nodes = be.grown(self.d_nodes, 8 * NODE_FIELDS * self.n_nodes, 8 * NODE_FIELDS * self.cap_nodes)
-        pool_entries = max(cap(plan["pool_used"]), 4)
-        if 4 * pool_entries > self.pool_cap:
-            self.pool_cap = 4 * pool_entries
-            self.d_pool = be.empty(self.pool_cap)
         uoffs = np.zeros(MAX_CLUSTERS + 1, np.int32)
         for k_, o_ in self._uoff.items():
             uoffs[k_] = o_
         self._uoffs_host = uoffs
         small = bool(KM_MODE & 2)
-        self._set(NODES=self.d_nodes, POOL=self.d_pool, DS=d_ds, UNIFORMS=self._d_uni, LOOP_FORMS=(1 | 8 | 2 | 4) if small else 1)
+        self._set(DS=d_ds, UNIFORMS=self._d_uni, LOOP_FORMS=(1 | 8 | 2 | 4) if small else 1)
         self.F[FI["SIDE_STREAM"]] = be.side_ptr(0) if (small and KM_SIDE_STREAMS and be.n_side_streams >= 1 and be.side_ptr(0) != be.stream) else 0
         self.F[FI["UOFF_HOST"]] = uoffs.ctypes.data
         self.F[FI["MAX_ROWS"]] = int(self.meta_arr[self.ok, 4].max()) if len(self.ok) else 1          # no view has more rows than its root
-        C = FI["CAP"]
-        self.F[C + CAP_NODES], self.F[C + CAP_POOL] = self.cap_nodes, self.pool_cap // 4
-        reps = []
-        for li in range(nL + 1):
-            keep = self._level_speculative(li, levels[li] if li < nL else None, cap)
-            reps.append(keep)
-            self.counters["launches"] += 1
-        return plan, d_ds, n_words, reps
+        self.F[FI["CAP"] + CAP_BIG] = max(KM_BIG_BYTES - 1, 0)
+        st = dict(caps=caps, d_ds=d_ds, n_words=n_words, reps=[], rec=[], done=0, tries=0)
+        self._spec_levels(st, 0)
+        return st
 
-    def _forest_speculative_finish(self, plan, d_ds, n_words, reps) -> bool:
-        """The ONE wait of a forest enqueued from a plan, and one look at the device state.  False: some total did not fit (or the
-        forest has more levels than the plan): nothing of the attempt is kept."""
+    def _spec_levels(self, st, L: int):
+        """Node table and row pool for the whole forest (no growing on the way), then levels L .. of the capacities + the level that
+        must find an empty frontier."""
+        be, caps = self.be, st["caps"]
+        C = FI["CAP"]
+        need_nodes = max(self.cap_nodes, int(caps["n_nodes"]))
+        if 8 * NODE_FIELDS * need_nodes > len(self.d_nodes):
+            self.d_nodes = be.grown(self.d_nodes, 8 * NODE_FIELDS * self.n_nodes, 8 * NODE_FIELDS * need_nodes)
+        self.cap_nodes = need_nodes
+        pool_entries = max(int(caps["pool"]), 4)
+        if 4 * pool_entries > self.pool_cap:
+            self.d_pool = be.grown(self.d_pool, 4 * self.pool_used, 4 * pool_entries) if self.pool_used else be.empty(4 * pool_entries)
+            self.pool_cap = 4 * pool_entries
+        self._set(NODES=self.d_nodes, POOL=self.d_pool)
+        self.F[C + CAP_NODES], self.F[C + CAP_POOL] = self.cap_nodes, self.pool_cap // 4
+        levels = caps["levels"]
+        del st["reps"][L:]
+        for li in range(L, len(levels) + 1):
+            st["reps"].append(self._level_speculative(li, levels[li] if li < len(levels) else None, int))
+            self.counters["launches"] += 1
+
+    def _spec_finish(self, st) -> bool:
+        """The ONE wait of a forest enqueued from capacities, and one look at the device state.  A total that did not fit: the
+        levels before it are kept, that level and the ones after it are enqueued again with more room (another wait) — or, when
+        that has not settled it (SPEC_RETRIES) or the level holds a BIG clustering problem, left to the per-step host.  Returns
+        whether the whole forest came from the device-counted path."""
         be = self.be
-        levels = plan["levels"]
-        nL = len(levels)
-        ds = be.download(d_ds, np.int64, n_words)
-        self.counters["syncs"] = self.counters.get("syncs", 0) + 1
-        if ds[DS_OVERFLOW] or ds[DS_N]:
-            return False
-        rec = []
-        for li in range(nL):
+        while True:
+            caps, d_ds = st["caps"], st["d_ds"]
+            ds = be.download(d_ds, np.int64, st["n_words"])
+            self.counters["syncs"] = self.counters.get("syncs", 0) + 1
+            code = int(ds[DS_OVERFLOW])
+            if not code and ds[DS_N]:          # (not reachable: the last level enqueued has no room and flags a frontier)
+                code = 100 * (int(ds[DS_LEVEL]) + 1) + STEP_BEGIN
+            n_done = (code // 100 - 1) if code else len(caps["levels"])
+            self._spec_note_levels(st, ds, n_done)
+            if not code:
+                break
+            L, step = code // 100 - 1, code % 100
+            self.counters["plan_misses"] = self.counters.get("plan_misses", 0) + 1
+            fb = ds[DS_GLOBAL + L * DS_LEVEL_WORDS:DS_GLOBAL + (L + 1) * DS_LEVEL_WORDS].reshape(6, HDR)
+            st["tries"] += 1
+            if step == STEP_SIZES_SHAPE or st["tries"] > SPEC_RETRIES or L + 2 + SPEC_SPARE_LEVELS > (st["n_words"] - DS_GLOBAL) // DS_LEVEL_WORDS:
+                self._forest_exact_resume(st, fb)
+                return False
+            self._caps_grow(caps, L, fb)
+            be.call("mprg_forest_state_rewind", be.ptr(d_ds), L, be.stream)
+            self.n_nodes, self.pool_used = int(fb[0][16]), int(fb[0][17])          # (what a grown node table / row pool must keep)
+            self._spec_levels(st, L)
+        self.n_nodes, self.pool_used = int(ds[DS_NNODES]), int(ds[DS_POOL_USED])
+        self._spec_failed = bool(ds[DS_NFAILED])
+        self._set(N_NODES=self.n_nodes, POOL_USED=self.pool_used)
+        self._plan = dict(key=self._roots_args[2], levels=st["rec"], n_nodes=self.n_nodes, pool_used=self.pool_used)
+        return True
+
+    def _spec_note_levels(self, st, ds, n_done: int):
+        """Levels st['done'] .. n_done - 1 are complete on the device: their totals (the next plan), counters, leaf tables."""
+        for li in range(st["done"], n_done):
             blk = ds[DS_GLOBAL + li * DS_LEVEL_WORDS:DS_GLOBAL + (li + 1) * DS_LEVEL_WORDS].reshape(6, HDR)
-            rec.append({s_: blk[s_].copy() for s_ in range(6)})
-            rec[-1]["rpc_idx"] = levels[li]["rpc_idx"]
+            st["rec"].append({s_: blk[s_].copy() for s_ in range(6)})
+            st["rec"][-1]["rpc_idx"] = st["caps"]["levels"][li]["rpc_idx"]
             b0, b1, b2, b4 = blk[0], blk[1], blk[2], blk[4]
             self.counters["levels"] += 1
             self.counters["cells_all"] += float(b0[11])
@@ -344,12 +485,19 @@ class ForestEngine(BatchEngine):
                 raise MprgError("k-mer dictionary: no hash seed separated the k-mers of a clustering problem (k-mer size > 16)")
             if b4[15]:
                 raise MprgError("a k-mer count matrix has more than 4 194 304 features: beyond the KMeans kernels' pairwise-sum stack")
-            self.levels.append(dict(f0=int(b0[13]), n=int(b0[14]), reps_pos=reps[li][0], reps_len=reps[li][1], reps_rows=int(b1[2])))
-        self.n_nodes, self.pool_used = int(ds[DS_NNODES]), int(ds[DS_POOL_USED])
-        self._spec_failed = bool(ds[DS_NFAILED])
-        self._set(N_NODES=self.n_nodes, POOL_USED=self.pool_used)
-        self._plan = dict(key=plan["key"], levels=rec, n_nodes=self.n_nodes, pool_used=self.pool_used)
-        return True
+            self.levels.append(dict(f0=int(b0[13]), n=int(b0[14]), reps_pos=st["reps"][li][0], reps_len=st["reps"][li][1], reps_rows=int(b1[2])))
+        st["done"] = max(st["done"], n_done)
+
+    def _forest_exact_resume(self, st, fb):
+        """The per-step host takes over at the level whose frontier block is fb (the levels before it came from the device-counted
+        path and stand)."""
+        self.counters["plan_resumes"] = self.counters.get("plan_resumes", 0) + 1
+        f0, n = int(fb[0][13]), int(fb[0][15])
+        self.n_nodes, self.pool_used = int(fb[0][16]), int(fb[0][17])
+        self._set(N_NODES=self.n_nodes, POOL_USED=self.pool_used, NODES=self.d_nodes, POOL=self.d_pool)
+        self._plan_rec = list(st["rec"])
+        self._big_seen = False
+        self._forest_exact_levels(f0, n)
 
     def _level_speculative(self, li: int, pl, cap):
         """Buffers of one level from the plan's totals `pl` (None: the level after the plan's last, which must find an empty
