@@ -422,7 +422,7 @@ int mprg_forest_level(const int64_t *F, void *stream);
  * again with larger buffers (mprg_forest_level, same MPRG_F_LEVEL_INDEX) — the levels before it stand.  Safe because a level's kernels
  * return at once from the overflow on and its only write that a second run would read differently (the nesting level of a new
  * MultiClusterNode, k_sp_children) comes after the level's last capacity check. */
-int mprg_forest_state_rewind(int64_t *ds, long long level, void *stream);
+int mprg_forest_state_rewind(int64_t *ds, long long n_words, long long level, void *stream);
 /* zeroes the device state (n_words int64) and sets the forest's roots: ds[MPRG_DS_N] = ds[MPRG_DS_NNODES] = n_roots */
 int mprg_forest_state_init(int64_t *ds, long long n_words, long long n_roots, void *stream);
 /* S1  frontier -> views.  hdr: 0 views, 1 their columns, 2 their rows, 3 fused views, 4 other views, 5-9 mask work items for

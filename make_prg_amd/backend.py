@@ -52,7 +52,7 @@ SIGNATURES = {
     "mprg_emit_alleles": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mprg_forest_level": (c_int, [c_void_p, c_void_p]),
     "mprg_forest_state_init": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_longlong, c_void_p]),
-    "mprg_forest_state_rewind": (c_int, [c_void_p, ctypes.c_longlong, c_void_p]),
+    "mprg_forest_state_rewind": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_longlong, c_void_p]),
     "mprg_forest_frontier_count": (c_int, [c_void_p, c_void_p]),
     "mprg_forest_frontier_fill": (c_int, [c_void_p, c_void_p]),
     "mprg_forest_classify": (c_int, [c_void_p, c_void_p]),

@@ -43,6 +43,8 @@ static const int g_dd_threads = env_threads("MPRG_DD_THREADS", BLOCK_VIEW, 512);
 static const int g_km_threads = env_threads("MPRG_KM_THREADS", 256);
 static const int g_km_wide_threads = env_threads("MPRG_KM_WIDE_THREADS", 1024);
 static const int g_kp_threads = env_threads("MPRG_KP_THREADS", 0);
+// small views by a wavefront each, several per workgroup (k_partition_wave, ...): MPRG_WAVE_VIEWS=0 keeps a workgroup per view
+static const int g_pw_wave = [] { const char *e = getenv("MPRG_WAVE_VIEWS"); return (e && atoi(e) == 0) ? 0 : 1; }();
 
 extern "C" {
 
@@ -124,9 +126,14 @@ static int d_partition(const uint8_t *arena, const int64_t *views, const int32_t
   if (n_other > 0)
     LAUNCH(k_partition, n_other, BLOCK_VIEW, stream, other_list, arena, views, rowidx, mask, min_match_length, maxrun, stack,
            ivflag, iv, n_iv, status, view_out, dc_other);
-  if (n_fused > 0)
+  if (n_fused > 0) {
+    // the fused list's SMALL views by a wavefront each (k_partition_wave: PW_WAVES per workgroup), the rest by a workgroup each:
+    // both launches walk the same list, each leaves the other's views alone
+    if (g_pw_wave) LAUNCH(k_partition_wave, (n_fused + PW_WAVES - 1) / PW_WAVES, PW_WAVES * WAVE, stream, fused_list, arena, views, rowidx,
+                          min_match_length, iv, n_iv, status, view_out, n_fused, dc_fused);
     LAUNCH(k_partition_fused, n_fused, g_pf_threads, stream, fused_list, arena, views, rowidx, min_match_length, iv, n_iv, status,
-           view_out, dc_fused);
+           view_out, g_pw_wave, dc_fused);
+  }
   if (view_out) {                                  // the packed list of all triples of the call
     if (!iv_packed || !iv_count) return fail("mprg_partition: view_out needs iv_packed and iv_count");
     LAUNCH(k_pack_scan, 1, 1024, stream, n_views, n_iv, view_out, iv_count, dc_views);
@@ -142,9 +149,13 @@ static int d_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int3
                           int32_t *reps_len, int32_t *seqrow, int64_t *occ_off, int64_t *summary, uint8_t *gcodes, void *stream,
                           DsCount dc_views, DsCount dc_rows, long long max_rows = 0) {
   if (n_views <= 0) return 0;
+  // the SMALL views by a wavefront each, all stages in one launch (k_dedupe_wave); the launches below leave them alone
+  if (g_pw_wave)
+    LAUNCH(k_dedupe_wave, (n_views + DW_WAVES - 1) / DW_WAVES, DW_WAVES * WAVE, stream, arena, views, rowidx, n_views, kmer_size, ucodes, gcodes, hashes,
+           ulen, rep_u, rep_g, d_of_row, s_of_row, reps_pos, reps_len, seqrow, occ_off, summary, dc_views);
   if (n_work_rows > 0) {
-    LAUNCH(k_ungap_hash, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, ucodes, hashes, ulen, gcodes, dc_rows);
-    LAUNCH(k_ungap_hash_u, n_work_rows, UG_ROWS, stream, views, work_rows, (const uint8_t *)ucodes, hashes, (const int32_t *)ulen, dc_rows);
+    LAUNCH(k_ungap_hash, n_work_rows, UG_ROWS, stream, arena, views, rowidx, work_rows, ucodes, hashes, ulen, gcodes, g_pw_wave, dc_rows);
+    LAUNCH(k_ungap_hash_u, n_work_rows, UG_ROWS, stream, views, work_rows, (const uint8_t *)ucodes, hashes, (const int32_t *)ulen, g_pw_wave, dc_rows);
     // views of more rows than k_ungap_dedupe's LDS table holds: their row groups by a scan over (view, 256-row chunk) work items.
     // A list with one chunk per view has no such view; a device-counted list (capacities here) goes by the caller's bound on
     // the rows of a view (max_rows; 0: none known).
@@ -153,7 +164,7 @@ static int d_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int3
              (const int32_t *)ulen, rep_u, rep_g, dc_rows);
   }
   LAUNCH(k_ungap_dedupe, n_views, g_dd_threads, stream, arena, views, rowidx, kmer_size, ucodes, (const uint8_t *)gcodes, hashes, ulen, rep_u, rep_g,
-         d_of_row, s_of_row, reps_pos, reps_len, seqrow, occ_off, summary, dc_views);
+         d_of_row, s_of_row, reps_pos, reps_len, seqrow, occ_off, summary, g_pw_wave, dc_views);
   return check_launch("k_ungap_dedupe");
 }
 int mprg_ungap_dedupe(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, int n_views, int kmer_size,
@@ -457,11 +468,12 @@ static int kf_publish(const int64_t *F, void *stream, const char *name) {
 // Every step exists once, for both ways of running a level: `ds` == nullptr — the step's own entry point, called by a host that
 // reads the totals back (hdr = MPRG_F_HDR, published to the host) — or the forest's device state — mprg_forest_level: the item
 // counts in F are CAPACITIES, the exact counts are words of ds, the step's totals go to its block `hdr` inside ds.
-struct KfStep { const int64_t *ds; int64_t *hdr; };
+// ck (optional, with ds): the capacity check of the step's totals, carried out by the launch that writes them (kf_scan)
+struct KfStep { const int64_t *ds; int64_t *hdr; const KfCheck *ck = nullptr; };
 static inline DsCount kf_dc(const KfStep &st, long long slot) { return DsCount{st.ds, (int)slot}; }
 static inline int kf_slot(const KfStep &st, const int64_t *word) { return st.ds ? (int)(word - st.ds) : 0; }
 static int kf_count_done(const int64_t *F, const KfStep &st, long long n, int m, DsCount dc, void *stream, const char *name) {
-  if (kf_scan(FP(int64_t, MPRG_F_VALS), n, m, st.hdr, FP(int64_t, MPRG_F_SCAN_TMP), stream, dc) != 0) return fail("scan");
+  if (kf_scan(FP(int64_t, MPRG_F_VALS), n, m, st.hdr, FP(int64_t, MPRG_F_SCAN_TMP), stream, dc, (int64_t *)st.ds, st.ck) != 0) return fail("scan");
   return st.ds ? check_launch(name) : kf_publish(F, stream, name);
 }
 static int kf_frontier_count(const int64_t *F, const KfStep &st, void *stream) {
@@ -537,7 +549,8 @@ static int kf_problems_fill(const int64_t *F, const KfStep &st, const int64_t *n
 static int kf_sizes_count(const int64_t *F, const KfStep &st, const int64_t *n_p, void *stream) {
   const long long P = F[MPRG_F_P];
   const DsCount dn = kf_dc(st, kf_slot(st, n_p));
-  if (hipMemsetAsync(st.hdr, 0, sizeof(int64_t) * MPRG_FOREST_HDR, (hipStream_t)stream) != hipSuccess) return fail("memset");
+  // (the header collects atomics; a block of the device state is zero already: mprg_forest_state_init / _rewind)
+  if (!st.ds && hipMemsetAsync(st.hdr, 0, sizeof(int64_t) * MPRG_FOREST_HDR, (hipStream_t)stream) != hipSuccess) return fail("memset");
   if (P > 0) LAUNCH(k_sz_count, KF_GRID(P), 256, stream, P, FP(const int64_t, MPRG_F_PTAB0), FP(const int32_t, MPRG_F_DV),
                     FP(const int64_t, MPRG_F_SUB), (int)F[MPRG_F_N_INIT], FP(int64_t, MPRG_F_VALS), st.hdr, dn);
   return kf_count_done(F, st, P, 9, dn, stream, "k_sz_count");
@@ -605,9 +618,10 @@ int mprg_forest_state_init(int64_t *ds, long long n_words, long long n_roots, vo
   LAUNCH(k_ds_init, 1, 64, stream, ds, n_roots);
   return check_launch("k_ds_init");
 }
-int mprg_forest_state_rewind(int64_t *ds, long long level, void *stream) {
-  if (!ds || level < 0) return fail("mprg_forest_state_rewind: no device state / negative level");
-  LAUNCH(k_ds_rewind, 1, 64, stream, ds, level);
+int mprg_forest_state_rewind(int64_t *ds, long long n_words, long long level, void *stream) {
+  if (!ds || level < 0 || MPRG_DS_GLOBAL + (level + 1) * MPRG_DS_LEVEL_WORDS > n_words)
+    return fail("mprg_forest_state_rewind: no device state / a level outside it");
+  LAUNCH(k_ds_rewind, 1, 64, stream, ds, level, n_words);
   return check_launch("k_ds_rewind");
 }
 // One recursion level, every step enqueued, nothing read back (include/mprg.h: "a recursion level WITHOUT a host wait").
@@ -619,15 +633,16 @@ int mprg_forest_level(const int64_t *F, void *stream) {
   auto blk = [&](int s) { return ds + MPRG_DS_GLOBAL + (L * 6 + s) * MPRG_FOREST_HDR; };
   auto slot = [&](const int64_t *w) { return DsCount{ds, (int)(w - ds)}; };
   const long long BIG = 0x7fffffffffffffffLL;
-  // caps: up to 16 column capacities (BIG: not limited), then two optional sum checks
+  // caps: up to 16 column capacities (BIG: not limited), then two optional sum checks — checked by the step's scan (kf_scan)
   auto check = [&](int step, int m, std::initializer_list<long long> caps, int col_a = -1, int field_a = 0, long long cap_a = 0, int col_b = -1,
-                   int field_b = 0, long long cap_b = 0, const int64_t *base = nullptr) {
-    DsCaps dcaps;
+                   int field_b = 0, long long cap_b = 0) {
+    KfCheck ck;
     int q = 0;
-    for (long long v : caps) dcaps.cap[q++] = v;
-    for (; q < 16; ++q) dcaps.cap[q] = BIG;
-    LAUNCH(k_ds_check, 1, 64, stream, ds, base ? base : (const int64_t *)blk(step), m, dcaps, 100 * (L + 1) + step, col_a, field_a, cap_a, col_b, field_b,
-           cap_b);
+    for (long long v : caps) ck.caps.cap[q++] = v;
+    for (; q < 16; ++q) ck.caps.cap[q] = BIG;
+    ck.m = m; ck.code = 100 * (L + 1) + step;
+    ck.col_a = col_a; ck.field_a = field_a; ck.cap_a = cap_a; ck.col_b = col_b; ck.field_b = field_b; ck.cap_b = cap_b;
+    return ck;
   };
   const uint8_t *arena = FP(const uint8_t, MPRG_F_ARENA);
   const int32_t *pool = FP(const int32_t, MPRG_F_POOL);
@@ -640,15 +655,12 @@ int mprg_forest_level(const int64_t *F, void *stream) {
     return check_launch("k_ds_advance");
   }
   int64_t *b0 = blk(MPRG_STEP_FRONTIER);
-  const KfStep st0{ds, b0};
+  long long item_caps[5] = {BIG, BIG, BIG, BIG, BIG};
+  item_caps[(int)F[MPRG_F_RPC_IDX]] = C[MPRG_CAP_ITEMS];
+  const KfCheck ck0 = check(MPRG_STEP_FRONTIER, 11, {cap_na, C[MPRG_CAP_TCOLS], BIG, C[MPRG_CAP_NFUSED], C[MPRG_CAP_NOTHER], item_caps[0], item_caps[1],
+                                                     item_caps[2], item_caps[3], item_caps[4], C[MPRG_CAP_NGAP]});
+  const KfStep st0{ds, b0, &ck0};
   if (kf_frontier_count(F, st0, stream) != 0) return -1;
-  {
-    const int rpc = (int)F[MPRG_F_RPC_IDX];
-    long long item_caps[5] = {BIG, BIG, BIG, BIG, BIG};
-    item_caps[rpc] = C[MPRG_CAP_ITEMS];
-    check(MPRG_STEP_FRONTIER, 11, {cap_na, C[MPRG_CAP_TCOLS], BIG, C[MPRG_CAP_NFUSED], C[MPRG_CAP_NOTHER], item_caps[0], item_caps[1], item_caps[2],
-                                   item_caps[3], item_caps[4], C[MPRG_CAP_NGAP]});
-  }
   if (cap_na > 0) {
     if (kf_frontier_fill(F, st0, stream) != 0) return -1;
     const int rpc = (int)F[MPRG_F_RPC_IDX];
@@ -665,11 +677,11 @@ int mprg_forest_level(const int64_t *F, void *stream) {
   }
   // ---- S2 classify, children of multi-interval nodes, the selected views
   int64_t *b1 = blk(MPRG_STEP_CLASSIFY);
-  const KfStep st1{ds, b1};
   const long long cap_sel = F[MPRG_F_NSEL];
+  const KfCheck ck1 = check(MPRG_STEP_CLASSIFY, 6, {BIG, cap_sel, C[MPRG_CAP_SROWS], C[MPRG_CAP_UBYTES], C[MPRG_CAP_SCOLS], C[MPRG_CAP_NDD]}, 0,
+                            MPRG_DS_NNODES, C[MPRG_CAP_NODES]);
+  const KfStep st1{ds, b1, &ck1};
   if (kf_classify(F, st1, b0 + 0, stream) != 0) return -1;
-  check(MPRG_STEP_CLASSIFY, 6, {BIG, cap_sel, C[MPRG_CAP_SROWS], C[MPRG_CAP_UBYTES], C[MPRG_CAP_SCOLS], C[MPRG_CAP_NDD]}, 0, MPRG_DS_NNODES,
-        C[MPRG_CAP_NODES]);
   if (kf_children(F, st1, stream) != 0) return -1;
   LAUNCH(k_ds_add, 1, 64, stream, ds, (int)MPRG_DS_NNODES, (const int64_t *)b1);
   int64_t *b5 = blk(MPRG_STEP_SPLITS);
@@ -681,10 +693,10 @@ int mprg_forest_level(const int64_t *F, void *stream) {
                        FP(int32_t, MPRG_F_REPS_LEN), FP(int32_t, MPRG_F_SEQROW), FP(int64_t, MPRG_F_OCC_OFF), FP(int64_t, MPRG_F_SUMMARY),
                        FP(uint8_t, MPRG_F_GCODES), stream, slot(b1 + 1), slot(b1 + 5), F[MPRG_F_MAX_ROWS]) != 0) return -1;
     int64_t *b2 = blk(MPRG_STEP_CLUSTER);
-    const KfStep st2{ds, b2};
     const long long cap_pq = F[MPRG_F_NPQ];
+    const KfCheck ck2 = check(MPRG_STEP_CLUSTER, 3, {cap_pq, C[MPRG_CAP_WC], C[MPRG_CAP_WR]});
+    const KfStep st2{ds, b2, &ck2};
     if (kf_cluster_count(F, st2, b1 + 1, stream) != 0) return -1;
-    check(MPRG_STEP_CLUSTER, 3, {cap_pq, C[MPRG_CAP_WC], C[MPRG_CAP_WR]});
     if (cap_pq > 0) {
       if (kf_cluster_fill(F, st2, b1 + 1, stream) != 0) return -1;
       // cluster_sequences.py:256: `while cluster_further(...)` is evaluated before any KMeans (k = 1, one cluster)
@@ -694,10 +706,10 @@ int mprg_forest_level(const int64_t *F, void *stream) {
                             nullptr, stream, slot(b2 + 1), slot(b2 + 2)) != 0) return -1;
       // ---- S4 the clustering problems, their k-mer dictionaries
       int64_t *b3 = blk(MPRG_STEP_PROBLEMS);
-      const KfStep st3{ds, b3};
       const long long cap_p = F[MPRG_F_P];
+      const KfCheck ck3 = check(MPRG_STEP_PROBLEMS, 4, {cap_p, C[MPRG_CAP_TABLE], C[MPRG_CAP_FLAG], C[MPRG_CAP_LO]});
+      const KfStep st3{ds, b3, &ck3};
       if (kf_problems_count(F, st3, b2 + 0, stream) != 0) return -1;
-      check(MPRG_STEP_PROBLEMS, 4, {cap_p, C[MPRG_CAP_TABLE], C[MPRG_CAP_FLAG], C[MPRG_CAP_LO]});
       if (cap_p > 0) {
         if (kf_problems_fill(F, st3, b2 + 0, stream) != 0) return -1;
         const DsCount dp = slot(b3 + 0);
@@ -706,10 +718,10 @@ int mprg_forest_level(const int64_t *F, void *stream) {
                FP(uint8_t, MPRG_F_FLAG), FP(int32_t, MPRG_F_DV), dp);
         // ---- S5 count matrices, workspaces, launch classes
         int64_t *b4 = blk(MPRG_STEP_SIZES);
-        const KfStep st4{ds, b4};
+        const KfCheck ck4 = check(MPRG_STEP_SIZES, 7, {C[MPRG_CAP_XD], C[MPRG_CAP_WSD], C[MPRG_CAP_CLS], C[MPRG_CAP_CLS + 1], C[MPRG_CAP_CLS + 2],
+                                                       C[MPRG_CAP_CLS + 3], C[MPRG_CAP_CLS + 4]});
+        const KfStep st4{ds, b4, &ck4};
         if (kf_sizes_count(F, st4, b3 + 0, stream) != 0) return -1;
-        check(MPRG_STEP_SIZES, 7, {C[MPRG_CAP_XD], C[MPRG_CAP_WSD], C[MPRG_CAP_CLS], C[MPRG_CAP_CLS + 1], C[MPRG_CAP_CLS + 2], C[MPRG_CAP_CLS + 3],
-                                   C[MPRG_CAP_CLS + 4]});
         // (b4[16 + c]: the largest LDS need of class c; class 4 = the global form, whose "need" is the size of the problem's count matrix:
         //  MPRG_CAP_BIG leaves a level that holds a BIG problem to the host, which has wider kernels for it; code: step 7)
         {
@@ -764,12 +776,11 @@ int mprg_forest_level(const int64_t *F, void *stream) {
           } else if (loop(forms, stream) != 0) return -1;
         }
         // ---- S7 MultiClusterNodes and their children
-        const KfStep st5{ds, b5};
         const long long cap_ns = F[MPRG_F_NSPLITS];
+        const KfCheck ck5 = check(MPRG_STEP_SPLITS, 3, {cap_ns, BIG, C[MPRG_CAP_NCHILD]}, 1, MPRG_DS_POOL_USED, C[MPRG_CAP_POOL], 2, MPRG_DS_NNODES,
+                                  C[MPRG_CAP_NODES]);
+        const KfStep st5{ds, b5, &ck5};
         if (kf_splits_count(F, st5, b3 + 0, stream) != 0) return -1;
-        check(MPRG_STEP_SPLITS, 1, {cap_ns}, 1, MPRG_DS_POOL_USED, C[MPRG_CAP_POOL], 2, MPRG_DS_NNODES, C[MPRG_CAP_NODES]);
-        LAUNCH(k_ds_check, 1, 64, stream, ds, (const int64_t *)b5, 3, DsCaps{{BIG, BIG, C[MPRG_CAP_NCHILD], BIG, BIG, BIG, BIG, BIG, BIG, BIG, BIG, BIG, BIG, BIG, BIG, BIG}},
-               100 * (L + 1) + MPRG_STEP_SPLITS, -1, 0, 0LL, -1, 0, 0LL);
         if (cap_ns > 0) {
           if (kf_splits_fill(F, st5, b3 + 0, stream) != 0) return -1;
           LAUNCH(k_split_children, cap_ns, 64, stream, FP(const int64_t, MPRG_F_SUB), pool, FP(const int64_t, MPRG_F_SPT), FP(const int64_t, MPRG_F_SP),

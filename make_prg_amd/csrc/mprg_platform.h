@@ -82,6 +82,21 @@ MPRG_DEV long long wave_scan_incl_ll(long long v) {
   for (int d = 1; d < WAVE; d <<= 1) { const long long y = __shfl_up(v, d); if (wave_lane() >= d) v += y; }
   return v;
 }
+// Lanes of ONE wavefront that exchange data through LDS without a workgroup barrier (several small work items per workgroup, a
+// wavefront each): the wavefront runs in lockstep, what has to be kept is the ORDER of its LDS accesses — the compiler must not
+// move them across this point and the earlier ones must have completed: a wavefront-scope fence.  Every lane of the wavefront
+// must reach it (converged control flow).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+// ... and through GLOBAL memory (a wavefront's stores before its other lanes' loads of them): workgroup scope — the CU's vector
+// L1 is shared by the workgroup's wavefronts, so this is a wait for the stores, not a cache operation
+#define WAVE_SYNC_GLOBAL() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); \
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+#else
+#define WAVE_SYNC() ((void)__ballot(1))
+#define WAVE_SYNC_GLOBAL() ((void)__ballot(1))
+#endif
 // exclusive prefix sum over ALL threads of a workgroup of up to 1024 threads (every thread calls it, uniform control
 // flow); *total receives the workgroup's sum.  scratch: 17 ints of LDS, reusable after the call returns.
 MPRG_DEV int block_scan_excl(int v, int *scratch, int *total) {

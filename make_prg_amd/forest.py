@@ -458,7 +458,7 @@ class ForestEngine(BatchEngine):
                 self._forest_exact_resume(st, fb)
                 return False
             self._caps_grow(caps, L, fb)
-            be.call("mprg_forest_state_rewind", be.ptr(d_ds), L, be.stream)
+            be.call("mprg_forest_state_rewind", be.ptr(d_ds), st["n_words"], L, be.stream)
             self.n_nodes, self.pool_used = int(fb[0][16]), int(fb[0][17])          # (what a grown node table / row pool must keep)
             self._spec_levels(st, L)
         self.n_nodes, self.pool_used = int(ds[DS_NNODES]), int(ds[DS_POOL_USED])
@@ -522,9 +522,21 @@ class ForestEngine(BatchEngine):
         n_splits, n_child = cap(h5[0]), cap(h5[2])
         self._scratch(max(n, nsel, n_pq, P, 1))
         e, z = be.empty, be.zeros
+        # the buffers that must arrive zeroed are places in ONE block: one fill per level instead of seven
+        al = lambda x: (int(x) + 255) // 256 * 256
+        zsizes = dict(MASK=4 * tcols, MAXRUN=4 * tcols, IVFLAG=8 * tcols, IVC=4)
+        if P:
+            zsizes.update(KM_STATUS=4 * P, ASSIGN=4 * lo, X=8 * xd)
+        zoff, ztotal = {}, 0
+        for name, nb in zsizes.items():
+            zoff[name] = ztotal
+            ztotal += al(max(nb, 16))
+        zslab = z(ztotal)
+        zbase = be.ptr(zslab)
+        self._alive["ZSLAB"] = zslab
         bufs = dict(VIEWS=e(8 * VF * na), VIEW2NODE=e(8 * na), FUSED_LIST=e(4 * n_fused), OTHER_LIST=e(4 * n_other), MASK_WORK=e(12 * n_items),
-                    GAP_WORK=e(8 * n_gap), VIEW_OUT=e(32 * na), IV_PACKED=e(12 * tcols), MASK=z(4 * tcols), MAXRUN=z(4 * tcols), STACK=e(16 * tcols),
-                    IVFLAG=z(8 * tcols), IV=e(12 * tcols), NIV=e(4 * na), STATUS=e(4 * na), IVC=z(4),
+                    GAP_WORK=e(8 * n_gap), VIEW_OUT=e(32 * na), IV_PACKED=e(12 * tcols), STACK=e(16 * tcols),
+                    IV=e(12 * tcols), NIV=e(4 * na), STATUS=e(4 * na),
                     SUB=e(8 * VF * nsel), SELNODE=e(8 * nsel), DD_WORK=e(8 * n_dd))
         caps = {CAP_TCOLS: tcols, CAP_NFUSED: n_fused, CAP_NOTHER: n_other, CAP_ITEMS: n_items, CAP_NGAP: n_gap, CAP_SROWS: srows, CAP_UBYTES: ubytes,
                 CAP_SCOLS: scols, CAP_NDD: n_dd, CAP_WC: n_wc, CAP_WR: n_wr, CAP_TABLE: table_bytes, CAP_FLAG: flag_bytes, CAP_LO: lo, CAP_XD: xd,
@@ -543,13 +555,15 @@ class ForestEngine(BatchEngine):
             bufs.update(T1=e(8 * PF * n_pq), WORK_COLS=e(8 * n_wc), WORK_ROWS=e(8 * n_wr), CF_SCRATCH=e(12 * scols + 64), FURTHER=e(4 * n_pq))
         if P:
             bufs.update(PTAB0=e(8 * PF * P), TABLE=e(table_bytes), FLAG=e(flag_bytes), DV=e(4 * P), PTAB=e(8 * PF * P),
-                        CLS_LISTS=e(4 * (PREPARE_CLASSES + 1) * P), NUM_CLUSTERS=e(4 * P), ACTIVE=e(4 * P), KM_INFO=e(64 * P), KM_STATUS=z(4 * P),
-                        X=z(8 * xd), WS=e(8 * wsd), LABELS=e(4 * lo), ASSIGN=z(4 * lo))
+                        CLS_LISTS=e(4 * (PREPARE_CLASSES + 1) * P), NUM_CLUSTERS=e(4 * P), ACTIVE=e(4 * P), KM_INFO=e(64 * P),
+                        WS=e(8 * wsd), LABELS=e(4 * lo))
         if n_splits:
             bufs.update(SPT=e(8 * PF * n_splits), SP=e(24 * n_splits), SPLITNODE=e(8 * n_splits), CHILD_SIZES=e(4 * n_child))
         for name in ("WORK_COLS", "WORK_ROWS") if not n_pq else ():
             F[FI[name]] = 0
         self._set(N=n, LVL=li, N_VIEWS=na, RPC_IDX=rpc_idx, NSEL=nsel, NPQ=n_pq, P=P, NSPLITS=n_splits, **bufs)
+        for name, off in zoff.items():
+            F[FI[name]] = zbase + off
         for q_, v_ in caps.items():
             F[C + q_] = v_
         be.call("mprg_forest_level", F.ctypes.data, be.stream)

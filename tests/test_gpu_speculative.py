@@ -54,3 +54,36 @@ def test_small_capacities_fall_back(hip, texts, step, col):
     reset(eng)
     eng.run_forest()
     assert eng.counters.get("plan_misses", 0) == 0 and eng.counters["syncs"] == 1 and dump(eng, 60) == first
+
+
+def test_first_seen_batch_is_sized_from_another_batch(hip, texts, monkeypatch):
+    """Capacities predicted from ANOTHER batch's totals (what the command line's chunks and a rank's shard get): same trees as the
+    per-step host, one wait per forest; with far too little room, levels are enqueued again / left to the per-step host."""
+    from make_prg_amd import forest
+    a_texts, b_texts = texts[0::2], texts[1::2]
+    a = ForestEngine(hip, 5, 7)
+    a.load([load_alignment_text(t) for t in a_texts])
+    a.run_forest()
+    donor = a.plan_export()
+    b0 = ForestEngine(hip, 5, 7)
+    b0.load([load_alignment_text(t) for t in b_texts])
+    b0.plan_donor = None
+    hip.plan_donor = None                      # (a's forest left its totals on the backend: this one must run the per-step host)
+    b0.run_forest()
+    waits_exact = b0.counters["syncs"]
+    want = dump(b0, len(b_texts))
+    for head, floor, retries in ((forest.PLAN_HEAD, forest.PLAN_FLOOR, forest.SPEC_RETRIES), (0.3, 0.0, 6), (0.3, 0.0, 1)):
+        monkeypatch.setattr(forest, "PLAN_HEAD", head)
+        monkeypatch.setattr(forest, "PLAN_FLOOR", floor)
+        monkeypatch.setattr(forest, "PLAN_SPREAD", forest.PLAN_SPREAD if head >= 1 else 0.0)
+        monkeypatch.setattr(forest, "SPEC_RETRIES", retries)
+        b = ForestEngine(hip, 5, 7)
+        b.load([load_alignment_text(t) for t in b_texts])
+        b.plan_donor = donor
+        b.run_forest()
+        waits, misses = b.counters["syncs"], b.counters["plan_misses"]
+        assert dump(b, len(b_texts)) == want
+        if head >= 1:
+            assert misses == 0 and waits == 1 and waits_exact > 20
+        else:
+            assert misses >= 1 and b.counters["plan_resumes"] == (1 if misses > retries else 0)

@@ -41,7 +41,8 @@ for s in range(steps):
           f"calls {eng.counters['launches']}", flush=True)
 be.synchronize()
 for name, evs in be.profile.items():          # per launch: the clustering loop / KMeans launches of every level
-    if "cluster_loop" in name or "kmeans_fit" in name:
+    if "cluster_loop" in name or "kmeans_fit" in name or (os.environ.get("MPRG_PROFILE_ALL_LAUNCHES") and name in
+                                                            ("mprg_partition", "mprg_ungap_dedupe", "mprg_cluster_further", "mprg_kmeans_prepare", "mprg_column_masks")):
         print(f"  per launch {name}: " + " ".join(f"{a.elapsed_time(b):.2f}" for a, b, _ in evs))
 prof = be.profile_summary()
 tot = sum(v["ms"] for v in prof.values())
