@@ -101,6 +101,7 @@ _CAP_COLS = {(0, 0): (0, 14), (0, 1): (0, 0), (0, 3): (0, 14), (0, 4): (0, 14), 
 PLAN_HEAD = float(os.environ.get("MPRG_PLAN_HEAD", "1.35"))          # headroom of a predicted total ...
 PLAN_SPREAD = float(os.environ.get("MPRG_PLAN_SPREAD", "24"))        # ... + this / sqrt(items behind it)
 PLAN_FLOOR = float(os.environ.get("MPRG_PLAN_FLOOR", "8"))           # room for this many more items of the donor's largest average size
+PLAN_TRACE = os.environ.get("MPRG_PLAN_TRACE", "") not in ("", "0")
 DONOR_MIN_ROOTS = int(os.environ.get("MPRG_DONOR_MIN_ROOTS", "16"))  # a forest of fewer alignments is nobody's donor
 DONOR_MAX_RATIO = 32.0
 SPEC_RETRIES = int(os.environ.get("MPRG_SPEC_RETRIES", "6"))         # levels enqueued again after an overflow before the per-step host takes over
@@ -453,6 +454,12 @@ class ForestEngine(BatchEngine):
             L, step = code // 100 - 1, code % 100
             self.counters["plan_misses"] = self.counters.get("plan_misses", 0) + 1
             fb = ds[DS_GLOBAL + L * DS_LEVEL_WORDS:DS_GLOBAL + (L + 1) * DS_LEVEL_WORDS].reshape(6, HDR)
+            if PLAN_TRACE:          # which totals did not fit (diagnostic)
+                lv = caps["levels"][L] if L < len(caps["levels"]) else None
+                over = [(st_, c_, int(fb[st_][c_]), int(lv[st_][c_])) for (st_, c_) in _CAP_COLS if lv is not None and fb[st_][c_] > lv[st_][c_]]
+                import sys
+                sys.stderr.write(f"[plan] overflow level {L} step {step} (try {st['tries'] + 1}): frontier {int(fb[0][15])} / {int(lv[0][14]) if lv is not None else 0}, "
+                                 f"nodes {int(fb[0][16])} / {caps['n_nodes']}, pool {int(fb[0][17])} / {caps['pool']}; (step, column, seen, room): {over}\n")
             st["tries"] += 1
             if step == STEP_SIZES_SHAPE or st["tries"] > SPEC_RETRIES or L + 2 + SPEC_SPARE_LEVELS > (st["n_words"] - DS_GLOBAL) // DS_LEVEL_WORDS:
                 self._forest_exact_resume(st, fb)

@@ -93,8 +93,19 @@ def balanced_parts(files: List[Path], n_parts: int) -> List[List[Path]]:
 
 
 def shard_files(files: List[Path], rank: int, world: int) -> List[Path]:
-    """This rank's cost-balanced shard of the input list."""
-    return balanced_parts(files, world)[rank]
+    """This rank's shard of the input list: a CONTIGUOUS stretch of the run's sorted loci (the order of every output file,
+    utils/input_output_files.py:89), cut where the cumulative file size crosses rank / world of the total — so a rank's part of every
+    output file is one byte range (utils/segments.py: every rank places its own bytes), and the shards are balanced by size to
+    within one file (a 30 000-gene pan-genome: thousands of files per rank)."""
+    from ..pipeline import sort_key
+    ordered = sorted(files, key=sort_key)
+    sizes = np.asarray([f.stat().st_size for f in ordered], np.float64)
+    total = float(sizes.sum())
+    if total <= 0:
+        return ordered[rank::world]
+    mid = np.cumsum(sizes) - sizes / 2.0                   # a file belongs to the rank its midpoint falls into
+    owner = np.minimum((mid * world / total).astype(np.int64), world - 1)
+    return [f for f, o in zip(ordered, owner.tolist()) if o == rank]
 
 
 def _load_one(args):
@@ -268,9 +279,9 @@ def write_final_files(all_loci: Dict[str, dict], output_type, output_prefix: str
 GATHER_ROUND_BYTES = int(os.environ.get("MPRG_GATHER_ROUND_BYTES", str(1 << 30)))
 
 
-def gather_bytes(payload: bytes, dist, rank: int, world: int):
-    """all_gather of the ranks' byte counts, then the payloads gathered on rank 0 as uint8 (RCCL moves device tensors, gloo host
-    tensors), in rounds of at most GATHER_ROUND_BYTES per rank.  Returns the list of the ranks' payloads on rank 0, None elsewhere.
+def allgather_bytes(payload: bytes, dist, rank: int, world: int):
+    """all_gather of the ranks' byte counts, then of the payloads as uint8 (RCCL moves device tensors, gloo host tensors), in rounds
+    of at most GATHER_ROUND_BYTES per rank.  Returns the list of the ranks' payloads, on every rank.
     What travels is each rank's segment index (loci, record lengths, members' CRC / size / offset: ~100 bytes per locus) — the
     outputs themselves stay in the files the ranks wrote (utils/segments.py)."""
     import torch
@@ -281,41 +292,93 @@ def gather_bytes(payload: bytes, dist, rank: int, world: int):
     dist.all_gather(sizes, torch.tensor([payload.size], dtype=torch.int64, device=dev))
     sizes = [int(t.item()) for t in sizes]
     cap = max(max(sizes), 1)
-    host = [np.empty(n, np.uint8) for n in sizes] if rank == 0 else None
+    host = [np.empty(n, np.uint8) for n in sizes]
     for lo in range(0, cap, GATHER_ROUND_BYTES):
         n = min(GATHER_ROUND_BYTES, cap - lo)
         mine = torch.zeros(n, dtype=torch.uint8, device=dev)
         seg = payload[lo:lo + n]
         if seg.size:
             mine[:seg.size] = torch.from_numpy(seg.copy()).to(dev)
-        parts = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-        dist.gather(mine, parts, dst=0)
-        if rank == 0:
-            for r, t in enumerate(parts):
-                take = max(0, min(sizes[r] - lo, n))
-                if take:
-                    host[r][lo:lo + take] = t[:take].cpu().numpy()
+        parts = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        for r, t in enumerate(parts):
+            take = max(0, min(sizes[r] - lo, n))
+            if take:
+                host[r][lo:lo + take] = t[:take].cpu().numpy()
         del parts, mine
-    return [h.tobytes() for h in host] if rank == 0 else None
+    return [h.tobytes() for h in host]
+
+
+def hip_runtimes_mapped() -> List[str]:
+    """The distinct HIP runtime libraries mapped into this process (/proc/self/maps).  A rank runs the library's kernels AND
+    torch.distributed (RCCL): both must sit on ONE copy of the runtime — two copies mean two sets of streams, devices and contexts
+    that know nothing of each other."""
+    seen = set()
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                path = line.rsplit(None, 1)[-1] if "/" in line else ""
+                if "libamdhip64" in os.path.basename(path):
+                    seen.add(os.path.realpath(path))
+    except OSError:
+        pass
+    return sorted(seen)
+
+
+def segment_prefix(options, rank: int, files: List[Path]) -> str:
+    """Where this rank writes its segment files: in memory (/dev/shm) when the shard's outputs fit comfortably (they are ~4x the
+    inputs with -O a), else next to the run's output.  MPRG_SEGMENT_DIR overrides."""
+    base = f"{os.path.basename(options.output_prefix)}.rank{rank}"
+    seg_dir = os.environ.get("MPRG_SEGMENT_DIR")
+    if seg_dir is None:
+        seg_dir = os.path.dirname(os.path.abspath(options.output_prefix))
+        try:
+            need = 6 * sum(f.stat().st_size for f in files)
+            st = os.statvfs("/dev/shm")
+            avail_kib = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1])
+            world_local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+            if need * world_local < 0.5 * min(st.f_bavail * st.f_frsize, avail_kib * 1024):
+                seg_dir = "/dev/shm"
+        except Exception:
+            pass
+    if seg_dir == "/dev/shm":
+        base = f"mprg_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{base}"
+    return os.path.join(seg_dir, base)
 
 
 def run_ranks(mine: List[Path], options, backend, dist, rank: int, world: int) -> int:
-    """A rank of a multi-GPU run: its size-balanced shard through the streamed one-GPU pipeline into SEGMENT files of its own; the
-    segment indexes gathered on rank 0 (the job's one collective); rank 0 merges the segments' byte ranges into the run's files
-    (utils/segments.py) — in the reference's order: every output lists the loci sorted (utils/input_output_files.py:89).
-    Returns the number of loci built (rank 0; 0 elsewhere)."""
+    """A rank of a multi-GPU run: its shard — a contiguous stretch of the run's sorted loci — through the streamed one-GPU pipeline
+    into SEGMENT files of its own; the segment indexes all-gathered (the job's one collective); then every rank copies ITS bytes to
+    their final offsets in the run's files, which rank 0 created and closes with the central directories (utils/segments.py) — in
+    the reference's order: every output lists the loci sorted (utils/input_output_files.py:89).  Returns the number of loci built."""
     import copy
+    import time
     from ..device import get_backend
-    from ..pipeline import run_pipeline, sort_key
+    from ..pipeline import run_pipeline
     from ..utils import segments
     opts = copy.copy(options)
-    opts.output_prefix = f"{options.output_prefix}.rank{rank}"
-    idx = run_pipeline(mine, opts, backend or (lambda: get_backend("runtime")), segment=True)
-    got = gather_bytes(segments.pack_index(idx), dist, rank, world)
-    n = 0
-    if rank == 0:
+    opts.output_prefix = segment_prefix(options, rank, mine)
+    t0 = time.perf_counter()
+    try:
+        idx = run_pipeline(mine, opts, backend or (lambda: get_backend("runtime")), segment=True)
+        libs = hip_runtimes_mapped()
+        if len(libs) > 1:
+            raise RuntimeError("two HIP runtimes are mapped into this rank (" + ", ".join(libs) + "): the kernels' library and "
+                               "torch.distributed must share one — import torch before the backend is made")
+        t1 = time.perf_counter()
+        got = allgather_bytes(segments.pack_index(idx), dist, rank, world)
+        t2 = time.perf_counter()
         n = segments.merge_segments([segments.unpack_index(b) for b in got], options.output_prefix,
-                                    sort_key=lambda locus: locus + ".prg.fa")
+                                    sort_key=lambda locus: locus + ".prg.fa", rank=rank, world=world, barrier=dist.barrier)
+        t3 = time.perf_counter()
+        logger.info(f"rank {rank}: segments built and written in {t1 - t0:.2f}s, index exchange {t2 - t1:.2f}s, placed in the run's files in {t3 - t2:.2f}s")
+        run_ranks.timings = dict(build_write_s=t1 - t0, exchange_s=t2 - t1, place_s=t3 - t2)
+    finally:
+        for suffix in (".prg.fa", ".prg.bin.zip", ".prg.gfa.zip", ".update_DS.zip"):          # (an error on the way: no stray segment)
+            try:
+                os.remove(opts.output_prefix + suffix)
+            except OSError:
+                pass
     return n
 
 

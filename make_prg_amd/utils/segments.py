@@ -1,13 +1,16 @@
-"""Merging the ranks' output SEGMENTS of a multi-GPU from_msa run into the run's files (reference
+"""Placing the ranks' output SEGMENTS of a multi-GPU from_msa run into the run's files (reference
 utils/input_output_files.py:73-162: per-locus temp files of every worker concatenated — sorted — and zipped at the end).
 
-Every rank streams its shard through the one-GPU pipeline (pipeline.py) into files of its own: `<prefix>.rank<r>.prg.fa`, the
-containers as STORED zips.  A stored member is a local header and the data, contiguous and position-independent; a `.prg.fa`
-record is two lines.  So the run's files are byte RANGES of the segments in the run's locus order plus one new central directory
-per container: rank 0 gets every rank's index (loci, record lengths, members' CRC / size / offset: a few MB through the job's one
-collective), copies the ranges inside the kernel (copy_file_range, falling back to read/write) and writes the directories.  The
-result equals what one rank writes for the whole input, byte for byte.  Nothing of the payload (22 GB for 30 000 loci with -O a)
-crosses RCCL or Python."""
+Every rank streams its shard through the one-GPU pipeline (pipeline.py) into files of its own: `<segment prefix>.prg.fa`, the
+containers as STORED zips — in memory (/dev/shm) when the shard's outputs fit, next to the output otherwise.  A stored member is a
+local header and the data, contiguous and position-independent; a `.prg.fa` record is two lines.  So the run's files are byte
+RANGES of the segments in the run's locus order plus one new central directory per container.  Every rank gets every rank's index
+(loci, record lengths, members' CRC / size / offset: ~100 bytes per locus through the job's one collective), so every rank knows
+where ITS bytes go: rank 0 creates the files at their final sizes, every rank copies its own ranges to their final offsets side by
+side (copy_file_range, falling back to read/write; a rank's shard is a contiguous stretch of the run's sorted loci —
+subcommands/from_msa.shard_files — so that is one range per file), rank 0 writes the directories.  No rank copies another rank's
+bytes (round 4: rank 0 copied all 22 GB of a 30 000-locus -O a run after the ranks had finished).  The result equals what one
+rank writes for the whole input, byte for byte.  Nothing of the payload crosses RCCL or Python."""
 import json
 import os
 import struct
@@ -52,9 +55,14 @@ def _copy_range(src_fd: int, dst_fd: int, src_off: int, dst_off: int, n: int):
         n -= len(buf); src_off += len(buf); dst_off += len(buf)
 
 
-def _copy_plan(dst_path: str, seg_paths: List[str], seg: np.ndarray, src_off: np.ndarray, length: np.ndarray, dst_off: np.ndarray):
+def _copy_plan(dst_path: str, seg_paths: List[str], seg: np.ndarray, src_off: np.ndarray, length: np.ndarray, dst_off: np.ndarray,
+               only_rank=None):
     """Copies piece q = length[q] bytes of segment seg[q] @ src_off[q] to dst_off[q]; neighbouring pieces of one segment that are
-    neighbours in the destination too go as one range; a few threads share the ranges."""
+    neighbours in the destination too go as one range; a few threads share the ranges.  only_rank: the pieces of that segment
+    only (every rank places its own bytes)."""
+    if only_rank is not None:
+        sel = seg == only_rank
+        seg, src_off, length, dst_off = seg[sel], src_off[sel], length[sel], dst_off[sel]
     n = len(seg)
     if n == 0:
         return
@@ -63,7 +71,10 @@ def _copy_plan(dst_path: str, seg_paths: List[str], seg: np.ndarray, src_off: np
     run_id = np.cumsum(first) - 1
     starts = np.nonzero(first)[0]
     run_len = np.bincount(run_id, weights=length).astype(np.int64)
-    runs = list(zip(seg[starts].tolist(), src_off[starts].tolist(), dst_off[starts].tolist(), run_len.tolist()))
+    runs = []
+    for s_, so, do, ln in zip(seg[starts].tolist(), src_off[starts].tolist(), dst_off[starts].tolist(), run_len.tolist()):
+        for lo in range(0, max(ln, 1), 1 << 28):          # (a rank's whole container is one run: share it among the threads)
+            runs.append((s_, so + lo, do + lo, min(1 << 28, ln - lo)))
     dst_fd = os.open(dst_path, os.O_WRONLY)
     used = set(seg.tolist())          # (a rank without files wrote no segment)
     fds = [os.open(p, os.O_RDONLY) if r in used else -1 for r, p in enumerate(seg_paths)]
@@ -81,9 +92,15 @@ def _copy_plan(dst_path: str, seg_paths: List[str], seg: np.ndarray, src_off: np
                 os.close(fd)
 
 
-def merge_segments(indexes: List[dict], output_prefix: str, sort_key, keep_segments: bool = False) -> int:
+def merge_segments(indexes: List[dict], output_prefix: str, sort_key, keep_segments: bool = False, rank: int = 0, world: int = 1,
+                   barrier=None) -> int:
     """indexes[r]: rank r's segment_index (pipeline.py).  Writes <prefix>.prg.fa, .prg.bin(.zip), .prg.gfa(.zip), .update_DS.zip in
-    the run's locus order (sort_key(locus)) and removes the segments.  Returns the number of loci."""
+    the run's locus order (sort_key(locus)) and removes the segments.  Returns the number of loci.
+    world > 1: called by EVERY rank with the same indexes; rank 0 creates the files and writes the directories, every rank copies its
+    own segment's ranges (barrier(): the job's barrier, between the three steps).  world == 1: one caller does it all."""
+    solo = world == 1
+    only = None if solo else rank
+    sync = barrier if (barrier is not None and not solo) else (lambda: None)
     # ---- the run's order
     loci, rank_of, pos_in_rank = [], [], []
     for r, idx in enumerate(indexes):
@@ -99,6 +116,8 @@ def merge_segments(indexes: List[dict], output_prefix: str, sort_key, keep_segme
     order = sorted(range(n_loci), key=lambda q: sort_key(loci[q]))
     place = {loci[q]: p for p, q in enumerate(order)}          # locus -> its place in the run
     seg_prefix = [idx["prefix"] for idx in indexes]
+    plans = []          # (destination, segment paths, seg, src offsets, lengths, destination offsets)
+    writers = []        # rank 0: containers whose central directory is written after the copies
     # ---- <prefix>.prg.fa
     if have_fa:
         src_off = [np.cumsum([0] + [ln for _, ln in idx["fa"]])[:-1] if idx["fa"] else np.zeros(0, np.int64) for idx in indexes]
@@ -107,9 +126,10 @@ def merge_segments(indexes: List[dict], output_prefix: str, sort_key, keep_segme
         ln = np.asarray([indexes[rank_of[q]]["fa"][pos_in_rank[q]][1] for q in order], np.int64)
         do = np.cumsum(ln) - ln
         dst = output_prefix + ".prg.fa"
-        with open(dst, "wb") as fh:
-            fh.truncate(int(ln.sum()))
-        _copy_plan(dst, [p + ".prg.fa" for p in seg_prefix], seg, so, ln, do)
+        if rank == 0:
+            with open(dst, "wb") as fh:
+                fh.truncate(int(ln.sum()))
+        plans.append((dst, [p + ".prg.fa" for p in seg_prefix], seg, so, ln, do))
     # ---- the containers: members in the run's order, one new central directory
     for kind in kinds:
         members = []          # (place, rank, name, crc, size, offset in the segment)
@@ -127,21 +147,31 @@ def merge_segments(indexes: List[dict], output_prefix: str, sort_key, keep_segme
         seg = np.asarray([m[1] for m in members], np.int64)
         so = np.asarray([m[5] for m in members], np.int64)
         if single:
-            with open(dst, "wb") as fh:
-                fh.truncate(int(size[0]))
-            _copy_plan(dst, [p + _KIND_FILE[kind] for p in seg_prefix], seg, so + head, size, np.zeros(1, np.int64))
+            if rank == 0:
+                with open(dst, "wb") as fh:
+                    fh.truncate(int(size[0]))
+            plans.append((dst, [p + _KIND_FILE[kind] for p in seg_prefix], seg, so + head, size, np.zeros(1, np.int64)))
             continue
         ln = head + size
         do = np.cumsum(ln) - ln
-        w = StoredZipWriter(dst, threads=1)
-        w._open()
-        os.ftruncate(w.fd, int(ln.sum()))
-        w.entries = [(m[2].encode("utf-8"), int(m[3]) & 0xFFFFFFFF, int(m[4]), int(o)) for m, o in zip(members, do.tolist())]
-        w.offset = int(ln.sum())
-        _copy_plan(dst, [p + _KIND_FILE[kind] for p in seg_prefix], seg, so, ln, do)
+        if rank == 0:
+            w = StoredZipWriter(dst, threads=1)
+            w._open()
+            os.ftruncate(w.fd, int(ln.sum()))
+            w.entries = [(m[2].encode("utf-8"), int(m[3]) & 0xFFFFFFFF, int(m[4]), int(o)) for m, o in zip(members, do.tolist())]
+            w.offset = int(ln.sum())
+            writers.append(w)
+        plans.append((dst, [p + _KIND_FILE[kind] for p in seg_prefix], seg, so, ln, do))
+    sync()                # the files exist at their final sizes
+    for dst, paths, seg, so, ln, do in plans:
+        _copy_plan(dst, paths, seg, so, ln, do, only_rank=only)
+    sync()                # every rank's bytes are in place
+    for w in writers:
         w.close()
     if not keep_segments:
-        for p in seg_prefix:
+        for r, p in enumerate(seg_prefix):
+            if only is not None and r != only:
+                continue
             for suffix in [".prg.fa"] + list(_KIND_FILE.values()):
                 try:
                     os.remove(p + suffix)

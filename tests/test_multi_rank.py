@@ -109,6 +109,66 @@ def test_segment_index_round_trip_and_merge(tmp_path):
     assert not (tmp_path / "o.rank0.prg.fa").exists() and not (tmp_path / "o.rank1.prg.bin.zip").exists()
 
 
+def test_every_rank_places_its_own_bytes(tmp_path):
+    """The multi-rank form of the merge: every rank calls it with all indexes; rank 0 creates the files and writes the directories,
+    each rank copies only ITS segment's ranges (here the two ranks one after the other, the barrier a no-op: the ranges are
+    disjoint, so the order does not matter) — same files as the one-caller form."""
+    import shutil
+    import zlib
+    from make_prg_amd.utils import segments
+    from make_prg_amd.utils.zip_stream import StoredZipWriter
+    data = {0: {"a": b"A" * 5, "b": b"BBBB"}, 1: {"c": b"CC", "d": b"D" * 70000}}
+
+    def make(root):
+        idxs = []
+        for r, members in data.items():
+            prefix = str(root / f"seg.rank{r}")
+            open(prefix + ".prg.fa", "wb").write(b"".join(b">" + k.encode() + b"\n" + v + b"\n" for k, v in members.items()))
+            z = StoredZipWriter(prefix + ".prg.gfa.zip")
+            z.add_many([k + ".gfa" for k in members], [[v] for v in members.values()], [zlib.crc32(v) for v in members.values()],
+                       [len(v) for v in members.values()])
+            z.close()
+            idxs.append(dict(n=len(members), prefix=prefix, fa=[[k, len(k) + len(v) + 3] for k, v in members.items()],
+                             zips={"gfa": [[nb.decode(), crc, size, off] for nb, crc, size, off in z.entries]}))
+        return idxs
+
+    (tmp_path / "one").mkdir(); (tmp_path / "two").mkdir()
+    segments.merge_segments(make(tmp_path / "one"), str(tmp_path / "one" / "o"), sort_key=lambda l: l + ".prg.fa")
+    idxs = make(tmp_path / "two")
+    calls = []
+    for r in (0, 1):
+        n = segments.merge_segments(idxs, str(tmp_path / "two" / "o"), sort_key=lambda l: l + ".prg.fa", rank=r, world=2,
+                                    barrier=lambda: calls.append(r))
+        assert n == 4
+        assert not os.path.exists(idxs[r]["prefix"] + ".prg.fa")            # a rank removes its own segments ...
+        assert r == 1 or os.path.exists(idxs[1]["prefix"] + ".prg.fa")      # ... and leaves the others'
+    assert calls == [0, 0, 1, 1]
+    for name in ("o.prg.fa", "o.prg.gfa.zip"):
+        assert (tmp_path / "one" / name).read_bytes() == (tmp_path / "two" / name).read_bytes(), name
+    with zipfile.ZipFile(tmp_path / "two" / "o.prg.gfa.zip") as z:
+        assert z.testzip() is None and z.namelist() == ["a.gfa", "b.gfa", "c.gfa", "d.gfa"]
+
+
+def test_shards_are_contiguous_in_the_run_order(tmp_path):
+    """A rank's shard is a contiguous stretch of the run's sorted loci (so that its part of every output file is one byte range),
+    balanced by file size to within one file."""
+    from make_prg_amd.pipeline import sort_key
+    from make_prg_amd.subcommands.from_msa import shard_files
+    import random
+    rnd = random.Random(5)
+    files = []
+    for i in range(200):
+        p = tmp_path / f"g{rnd.randrange(10 ** 6):06d}_{i}.fa"
+        p.write_text("x" * rnd.randrange(100, 3000))
+        files.append(p)
+    order = sorted(files, key=sort_key)
+    for world in (2, 3, 8):
+        parts = [shard_files(files, r, world) for r in range(world)]
+        assert [f for part in parts for f in part] == order          # contiguous, in order, complete
+        loads = [sum(f.stat().st_size for f in part) for part in parts]
+        assert max(loads) - min(loads) <= 2 * 3000, loads
+
+
 def test_shards_are_disjoint_and_complete(tmp_path):
     from make_prg_amd.subcommands.from_msa import shard_files
     files = []
