@@ -298,6 +298,18 @@ int mprg_cluster_loop(const int64_t *views, const int64_t *prob, int n_probs, in
                       const uint8_t *gcodes, int32_t *scratch, int32_t *labels, int32_t *assign, double *km_info, int32_t *km_status,
                       int32_t *num_clusters, int32_t *active, int64_t *stats, int forms, void *stream);
 
+/* A12 — cluster_sequences.py:256-274, every round of the loop AT ONCE for levels that hold a few BIG problems: the KMeans fits of
+ * different k share nothing but the problem's read-only data, so the general-form fit of every k = 2 .. min(10, D - 1) of every
+ * problem can go out in ONE launch of mprg_kmeans_fit_wide (n_fits = 9 n_probs, fit_list = NULL) — ninety workgroups per problem
+ * instead of ten, nine times over — and the rounds then settle in the reference's order on results that are already there.  This
+ * writes the launch's table: kinfo_out int32 [9 n_probs][5], row (k - 2) n_probs + b = {b, k (0: round k's fit of this problem
+ * takes another form, or k >= D), restart slot (k - 2) n_init, uniform_offsets_host[k], (k - 2) labels_per_k}.  The problems'
+ * workspaces must hold 9 n_init restart slots (mprg_kmeans_workspace_doubles), labels / km_info / km_status nine slices of
+ * labels_per_k / 8 n_probs / n_probs entries: slice k - 2 is what round k's other launches and mprg_cluster_further are given.
+ * mode: MPRG_F_KM_MODE (which forms small fits take). */
+int mprg_kmeans_speculative_kinfo(const int64_t *prob, int n_probs, int n_init, int mode, const int32_t *uniform_offsets_host,
+                                  long long labels_per_k, int32_t *kinfo_out, void *stream);
+
 /* A12/A14 — cluster_sequences.py:287-296 + recursion_tree.py:558-572: row lists of the children of MultiClusterNodes.
  * split_info: n_probs x 3 int64 {number of KMeans clusters, offset of the problem's n_rows entries in pool_out,
  * offset of its child sizes in child_sizes}.  Children order: the cluster holding the first row, then the KMeans

@@ -231,8 +231,16 @@ int mprg_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcounts,
 int mprg_kmeans_prepare_big(const int64_t *prob, const double *xcounts, double *ws, const int32_t *list, int n_list, uint8_t *xbytes,
                             int with_tables, void *stream) {
   if (n_list <= 0) return 0;
-  LAUNCH(k_kmeans_prepare, n_list, 256, stream, list, prob, xcounts, ws, with_tables ? 0 : 1, xbytes, DS_HOST);
-  if (with_tables) LAUNCH(k_kmeans_prepare_tables, (long long)n_list * KP_PARTS, 256, stream, list, prob, xcounts, ws, xbytes, DS_HOST);
+  // the statistics by many workgroups per problem (k_kmeans_prepare_cols .. _norms: the values of k_kmeans_prepare's one workgroup)
+  LAUNCH2(k_kmeans_prepare_cols, n_list, KPS_PARTS, 256, stream, list, prob, xcounts, ws);
+  LAUNCH(k_kmeans_prepare_tol, n_list, 64, stream, list, prob, ws, with_tables ? 0 : 1, xbytes ? 1 : 0);
+  LAUNCH2(k_kmeans_prepare_centre, n_list, KPS_PARTS, 256, stream, list, prob, xcounts, ws, xbytes);
+  LAUNCH2(k_kmeans_prepare_norms, n_list, KPS_PARTS, 256, stream, list, prob, ws);
+  if (with_tables) {          // a few big problems: more workgroups per problem than the pan-genome launches' KP_PARTS
+    int parts = 4096 / n_list;
+    parts = parts < KP_PARTS ? KP_PARTS : (parts > 1024 ? 1024 : parts);
+    LAUNCH(k_kmeans_prepare_tables, (long long)n_list * parts, 256, stream, list, prob, xcounts, ws, xbytes, parts, DS_HOST);
+  }
   return check_launch("k_kmeans_prepare");
 }
 // dc: device count of the ONE list the call holds (device-counted calls pass either lds_list or other_list)
@@ -244,7 +252,7 @@ static int d_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcou
   if (n_lds > 0 && (lds_bytes <= 0 || lds_bytes > MPRG_KMEANS_PREPARE_LDS_MAX)) return fail("mprg_kmeans_prepare: lds_bytes out of range");
   if (n_other > 0) {
     LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws, 0, (uint8_t *)nullptr, dc);
-    LAUNCH(k_kmeans_prepare_tables, (long long)n_other * KP_PARTS, 256, stream, other_list, prob, xcounts, ws, (uint8_t *)nullptr, dc);
+    LAUNCH(k_kmeans_prepare_tables, (long long)n_other * KP_PARTS, 256, stream, other_list, prob, xcounts, ws, (uint8_t *)nullptr, KP_PARTS, dc);
   }
   if (n_lds > 0) {
     if (lds_bytes > 64 * 1024) {     // beyond the default per-workgroup limit: gfx950 has 160 KB of LDS per CU, one such workgroup fits
@@ -607,6 +615,15 @@ int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream) {
          FP(int32_t, MPRG_F_NUM_CLUSTERS), FP(int32_t, MPRG_F_ACTIVE), FP(int32_t, MPRG_F_KINFO), FP(const double, MPRG_F_KM_INFO), FP(int32_t, MPRG_F_KM_STATUS),
          FP(const int32_t, MPRG_F_FURTHER), (int)F[MPRG_F_UOFF + (k <= KM_KMAX ? k : 0)], FP(int32_t, MPRG_F_FIT_LISTS), FHDR);
   return kf_publish(F, stream, "k_kl_advance");
+}
+int mprg_kmeans_speculative_kinfo(const int64_t *prob, int n_probs, int n_init, int mode, const int32_t *uniform_offsets_host, long long labels_per_k,
+                                  int32_t *kinfo_out, void *stream) {
+  if (n_probs <= 0) return 0;
+  if (!uniform_offsets_host || !kinfo_out) return fail("mprg_kmeans_speculative_kinfo: uniform offsets / output missing");
+  KlUoffs u;
+  for (int k = 0; k <= KM_KMAX; ++k) u.v[k] = uniform_offsets_host[k];
+  LAUNCH(k_kl_speculate, KF_GRID((long long)n_probs * (KM_KMAX - 1)), 256, stream, (long long)n_probs, n_init, mode, prob, u, labels_per_k, kinfo_out);
+  return check_launch("k_kl_speculate");
 }
 int mprg_forest_splits_count(const int64_t *F, void *stream) { return kf_splits_count(F, KF_HOST, nullptr, stream); }
 int mprg_forest_splits_fill(const int64_t *F, void *stream) { return kf_splits_fill(F, KF_HOST, nullptr, stream); }

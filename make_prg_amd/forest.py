@@ -74,6 +74,9 @@ KM_BIG_BYTES = int(os.environ.get("MPRG_KM_BIG_BYTES", str(1 << 20)))
 # ... and from this size on the level's big problems are prepared WITHOUT the sample-sample tables of the seeding (mprg_kmeans_prepare_big, with_tables = 0:
 # 2.5 D^2 chains per problem); the wide fits then compute the few dozen rows they ask for themselves
 KM_NO_TABLES_BYTES = int(os.environ.get("MPRG_KM_NO_TABLES_BYTES", str(160 << 20)))
+# ... and a big level of at most this many problems fits EVERY round's general-form KMeans at once (_kloop_rounds, spec_k): a round is
+# ten wide workgroups per problem — with five problems fifty CUs of 256, nine rounds one after the other; 0 = never
+KM_SPEC_PROBLEMS = int(os.environ.get("MPRG_KM_SPEC_PROBLEMS", "64"))
 # k-mer dictionaries by KD_PARTS workgroups per problem when a level's problems hold this many k-mer occurrences on average (0 = never)
 KD_PARTS_FROM = int(os.environ.get("MPRG_KD_PARTS_FROM", str(1 << 17)))
 KD_PARTS = 128
@@ -682,6 +685,14 @@ class ForestEngine(BatchEngine):
             raise MprgError("k-mer dictionary: no hash seed separated the k-mers of a clustering problem (k-mer size > 16)")
         if h[15]:
             raise MprgError("a k-mer count matrix has more than 4 194 304 features: beyond the KMeans kernels' pairwise-sum stack")
+        # a level of a FEW BIG problems (the top of one deep alignment): every round's general-form fit at once (_kloop_rounds,
+        # mprg_kmeans_speculative_kinfo) — their workspaces hold the restart slots of nine rounds
+        spec_k = bool(KM_BIG_BYTES) and int(h[16:17 + PREPARE_CLASSES].max()) >= KM_BIG_BYTES and 0 < P <= KM_SPEC_PROBLEMS and N_INIT * (MAX_CLUSTERS - 1) <= 16 * 9
+        if spec_k:
+            self.F[FI["N_INIT"]] = N_INIT * (MAX_CLUSTERS - 1)
+            h = self._step("sizes_count", n_hdr=21)
+            self.F[FI["N_INIT"]] = N_INIT
+            self._plan_note(rec, 4, h)
         x_doubles, ws_doubles, n_wc, n_wr = int(h[0]), int(h[1]), int(h[7]), int(h[8])
         d_ptab, d_cls = be.empty(8 * PF * P), be.empty(4 * (PREPARE_CLASSES + 1) * P)
         d_numcl, d_active, d_kinfo = be.empty(4 * P), be.empty(4 * P), be.empty(20 * P)
@@ -751,7 +762,7 @@ class ForestEngine(BatchEngine):
             self.counters["launches"] += 2 if small else 1
         else:
             self._kloop_rounds(P, d_sub, d_ptab, d_kinfo, d_x, d_ws, d_labels, d_assign, d_info, d_st, d_wc, n_wc, d_wr, n_wr, d_scratch,
-                               d_further, dd, km_events, cf_events, wide=big, d_xb=d_xb)
+                               d_further, dd, km_events, cf_events, wide=big, d_xb=d_xb, spec_k=spec_k and big, lo=lo)
         # ---- S7: MultiClusterNodes and their children (cluster_sequences.py:276-296, recursion_tree.py:457-469)
         self._scratch(P)
         h = self._step("splits_count", n_hdr=HDR)
@@ -792,21 +803,43 @@ class ForestEngine(BatchEngine):
 
 
     def _kloop_rounds(self, P, d_sub, d_ptab, d_kinfo, d_x, d_ws, d_labels, d_assign, d_info, d_st, d_wc, n_wc, d_wr, n_wr, d_scratch,
-                      d_further, dd, km_events, cf_events, wide=False, d_xb=None):
+                      d_further, dd, km_events, cf_events, wide=False, d_xb=None, spec_k=False, lo=0):
         """The clustering loop as one set of launches per round k (rounds 1-3's shape; MPRG_KLOOP=rounds): the control step settles
-        the previous round on the device (k_kl_advance), a retired problem's workgroups return at once."""
+        the previous round on the device (k_kl_advance), a retired problem's workgroups return at once.
+        spec_k (a level of a few BIG problems): the general-form fit of EVERY round goes out first, in one launch of wide workgroups —
+        ninety per problem instead of ten nine times over; round k's other launches, its mprg_cluster_further and the control step of
+        round k + 1 then work on slice k - 2 of the labels / km_info / km_status arrays, where the round's fits already are."""
         be = self.be
         d_fl = be.empty(4 * len(KM_LISTS) * P)
         self._set(FIT_LISTS=d_fl, KM_MODE=KM_MODE)
         fit_args = (be.ptr(self._d_uni), be.ptr(d_x), be.ptr(d_ws))
-        out_args = (be.ptr(d_labels), be.ptr(d_info), be.ptr(d_st), be.stream)
+        n_k = MAX_CLUSTERS - 1
+        if spec_k:
+            uoffs = np.zeros(MAX_CLUSTERS + 1, np.int32)
+            for k_, o_ in self._uoff.items():
+                uoffs[k_] = o_
+            d_labels, d_info, d_st = be.empty(4 * n_k * max(lo, 1)), be.empty(64 * n_k * P), be.zeros(4 * n_k * P)
+            d_ki = be.empty(20 * n_k * P)
+            be.call("mprg_kmeans_speculative_kinfo", be.ptr(d_ptab), P, N_INIT, KM_MODE, uoffs.ctypes.data, lo, be.ptr(d_ki), be.stream)
+            be.call("mprg_kmeans_fit_wide", be.ptr(d_ptab), be.ptr(d_ki), 0, n_k * P, N_INIT, *fit_args, be.ptr(d_labels), be.ptr(d_info), be.ptr(d_st),
+                    be.ptr(d_xb) if d_xb is not None else 0, be.stream)
+            ev = self._last_event("mprg_kmeans_fit_wide")
+            km_events.append(ev and ev + ("mprg_kmeans_fit",))
+            self.counters["launches"] += 3
+            self.counters["speculative_levels"] = self.counters.get("speculative_levels", 0) + 1
+        # the arrays of round k (spec_k: slice k - 2; else the level's)
+        lab_of = lambda k: be.ptr(d_labels) + (4 * (k - 2) * lo if spec_k else 0)
+        info_of = lambda k: be.ptr(d_info) + (64 * (k - 2) * P if spec_k else 0)
+        st_of = lambda k: be.ptr(d_st) + (4 * (k - 2) * P if spec_k else 0)
         for k in range(2, MAX_CLUSTERS + 2):
+            if spec_k:          # the control step settles round k - 1: that round's results
+                self.F[FI["KM_INFO"]], self.F[FI["KM_STATUS"]] = info_of(max(k - 1, 2)), st_of(max(k - 1, 2))
             hk = self._step("kloop_advance", k, n_hdr=HDR)
             if k > MAX_CLUSTERS or hk[83] == 0:
                 break
             # the round's fits, already sorted into launch lists by the control step; the lists are independent launches of
             # different kernels: side by side on side streams, so that one list's tail (its last, longest fits) overlaps the others
-            todo = [(c, int(hk[86 + c])) for c in range(len(KM_LISTS)) if hk[86 + c]]
+            todo = [(c, int(hk[86 + c])) for c in range(len(KM_LISTS)) if hk[86 + c] and not (spec_k and KM_LISTS[c][1] is None)]
             # (not while per-entry-point events are recorded: they would time launches that overlap)
             n_side = len(todo) if (len(todo) > 1 and KM_SIDE_STREAMS and be.profile is None and be.n_side_streams >= len(todo)) else 0
             if n_side:
@@ -816,7 +849,7 @@ class ForestEngine(BatchEngine):
                 list_entry = entry                    # (the list's algorithmic bytes are credited under this name, split or not)
                 lst = be.ptr(d_fl) + 4 * c * P
                 stream = be.side_ptr(q) if n_side else be.stream
-                outs = out_args[:-1] + (stream,)
+                outs = (lab_of(k), info_of(k), st_of(k), stream)
                 if (wide and cls is None) or n_c <= KM_SPLIT_BELOW:          # (wide: a level with BIG problems, its general-form fits)
                     if wide and cls is None:          # (d_xb: the byte matrix mprg_kmeans_prepare_big wrote for the level's big problems)
                         entry = "mprg_kmeans_fit_wide"
@@ -834,8 +867,10 @@ class ForestEngine(BatchEngine):
                 self.counters["launches"] += 1 + (entry in ("mprg_kmeans_fit_split", "mprg_kmeans_fit_wide"))
             if n_side:
                 be.join(n_side)
-            self._cluster_further(d_sub, d_ptab, P, k, dd, d_labels, d_assign, d_wc, n_wc, d_wr, n_wr, d_scratch, d_further, d_info, d_kinfo)
+            self._cluster_further(d_sub, d_ptab, P, k, dd, lab_of(k), d_assign, d_wc, n_wc, d_wr, n_wr, d_scratch, d_further, info_of(k), d_kinfo)
             cf_events.append(self._last_event("mprg_cluster_further"))
+        if spec_k:
+            self._alive["SPEC_K"] = (d_labels, d_info, d_st, d_ki)          # (until the level ends: the stream still reads them)
 
     def _last_event(self, name):
         prof = self.be.profile
@@ -853,7 +888,7 @@ class ForestEngine(BatchEngine):
     def _cluster_further(self, d_sub, d_prob, n_probs, k, dd, d_labels, d_assign, d_wc, n_wc, d_wr, n_wr, d_scratch, d_further, d_info,
                          d_kinfo, work=0.0):
         be = self.be
-        p = lambda b: be.ptr(b) if b is not None else None
+        p = lambda b: (b if isinstance(b, int) else be.ptr(b)) if b is not None else None          # (a buffer, or an address inside one)
         be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(self.d_pool), be.ptr(d_prob), n_probs, k,
                 be.ptr(dd["d_of_row"]), p(d_labels), p(d_assign), be.ptr(d_wc), n_wc, be.ptr(d_wr), n_wr, be.ptr(d_scratch),
                 be.ptr(d_further), p(d_info), be.ptr(dd["gcodes"]), p(d_kinfo), be.stream, work=work)

@@ -190,6 +190,22 @@ def test_levels_with_big_problems_take_the_wide_fits(emu, monkeypatch, golden_in
     assert pc.check_integration(glob, golden_integration) >= 30
 
 
+@pytest.mark.parametrize("km_mode", [0, 2])
+def test_every_round_of_a_big_level_at_once(emu, monkeypatch, golden_integration, km_mode):
+    """forest.KM_SPEC_PROBLEMS: a big level of few problems launches the general-form fit of EVERY k = 2..10 at once (wide workgroups,
+    restart slots and result slices per k) and the loop's rounds settle on results that are already there — here every level
+    (threshold 1 byte, any number of problems), with every fit in the general form (km_mode 0) and with the small fits in their own
+    per-round launches beside the speculative ones (km_mode 2).  Same answers as the oracle / the real reference's goldens."""
+    import make_prg_amd.forest as F
+    monkeypatch.setattr(F, "KM_BIG_BYTES", 1)
+    monkeypatch.setattr(F, "KM_SPEC_PROBLEMS", 1 << 30)
+    monkeypatch.setattr(F, "KM_MODE", km_mode)
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    eng = pc.check_vs_oracle(emu, random_cases(53, 24), 5, 7)
+    assert eng._big_seen and eng.counters.get("speculative_levels", 0) >= 1
+    assert pc.check_integration(emu, golden_integration) >= 30
+
+
 @pytest.mark.parametrize("no_tables_from", [1, 1 << 40])
 def test_big_problem_through_the_byte_matrix(emu, monkeypatch, no_tables_from):
     """A clustering problem whose count matrix is beyond the LDS prepare classes (150 distinct sequences x ~250 4-mers: 300 KB) in a level
