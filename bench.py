@@ -658,13 +658,23 @@ def main():
                     raise RuntimeError(r.stderr[-400:])
                 dj = json.load(open(outj))
             ps = dj["passes"]
-            deep = dict(workload=f"one hierarchical alignment {gold['S']} x {gold['C']} (utils/synthetic.synth_rows_deep seed {gold['seed']}), -N {gold['N']} -L {gold['L']}",
+            # roofline of the deep leg's dominant entry point (the profiled pass: HIP events on the launch stream): algorithmic bytes
+            # 8 D V (iterations + n_init) of the fits it ran / its device time
+            top_e = max(ps[0].get("entry_points", [{}]), key=lambda e_: e_.get("ms", 0.0)) if ps[0].get("entry_points") else None
+            deep_roof = None
+            if top_e and top_e.get("achieved_GBps"):
+                deep_roof = dict(bound="hbm", entry_point=top_e["entry_point"], kernel=KERNEL_OF.get(top_e["entry_point"], "k_kmeans_restart_wide + k_kmeans_select_list"),
+                                 ms=top_e["ms"], launches=top_e["calls"], algorithmic_bytes=top_e["algorithmic_bytes"], achieved=top_e["achieved_GBps"],
+                                 peak=HBM_PEAK_GBS, unit="GB/s", frac=round(top_e["achieved_GBps"] / HBM_PEAK_GBS, 6),
+                                 traffic=None, traffic_note="FETCH_SIZE / WRITE_SIZE passes of the same command: profiles/r05/deep/")
+            deep = dict(roofline=deep_roof,workload=f"one hierarchical alignment {gold['S']} x {gold['C']} (utils/synthetic.synth_rows_deep seed {gold['seed']}), -N {gold['N']} -L {gold['L']}",
                         seconds=round(min(p_["wall_ms"] for p_ in ps) / 1e3, 3), nodes=ps[-1]["nodes"], levels=ps[-1]["levels"], kmeans_fits=ps[-1]["fits"],
                         prg_identical_to_the_fixture=all(p_["prg_sha256"] == gold["expect"]["prg_sha256"] for p_ in ps),
                         fixture="tests/golden/ddeep.json (PRG confirmed by the REAL reference: 293 s on this container's CPU)",
                         top_entry_points=[(e_["entry_point"], e_["ms"]) for e_ in ps[0].get("entry_points", [])[:4]],
                         region="resident alignment -> recursion forest (per-step host) + PRG text in pinned memory; levels with big clustering "
-                               "problems take mprg_kmeans_fit_wide (profiles/r04/deep_alignment.md)")
+                               "problems take mprg_kmeans_fit_wide, every round's fit at once where the level holds few problems "
+                               "(profiles/r05/deep_alignment.md)")
         except Exception as err:          # reported, not hidden
             deep = dict(error=f"{type(err).__name__}: {err}"[:400])
 

@@ -352,7 +352,10 @@ class ForestEngine(BatchEngine):
         def cap_of(lv, st, c):
             cs, cc = _CAP_COLS[(st, c)]
             pred, n_pred = (r * float(lv[st][c]), r * float(lv[cs][cc])) if lv is not None else (0.0, 0.0)
-            return int(np.ceil(pred * (PLAN_HEAD + PLAN_SPREAD / np.sqrt(n_pred + 1.0)) + PLAN_FLOOR * unit[(st, c)]))
+            # the items that effectively make up the total: the counted ones — or fewer: a count of RARE items (the problems of one
+            # LDS class among thousands: 12 predicted, 30 seen) scatters like its own value, a total of a few big items like their number
+            n_eff = min(n_pred, pred / max(unit[(st, c)], 1.0))
+            return int(np.ceil(pred * (PLAN_HEAD + PLAN_SPREAD / np.sqrt(n_eff + 1.0)) + PLAN_FLOOR * unit[(st, c)]))
 
         levels, n_front = [], len(ok)
         n_nodes, pool = len(ok), 0

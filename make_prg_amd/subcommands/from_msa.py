@@ -39,7 +39,10 @@ def register_parser(subparsers):
     p.add_argument("-o", "--output-prefix", dest="output_prefix", action="store", type=str, required=True,
                    help="Prefix for the output files")
     p.add_argument("-f", "--alignment-format", dest="alignment_format", action="store", default="fasta",
-                   help="Alignment format of MSA: fasta, clustal, stockholm, phylip, phylip-sequential, phylip-relaxed. Default: %(default)s")
+                   help="Alignment format of MSA. fasta (default: %(default)s) is read exactly as the reference reads it (every golden file of "
+                        "the reference is FASTA).  clustal, stockholm, phylip, phylip-sequential, phylip-relaxed are BEST-EFFORT restatements of "
+                        "Biopython's readers (not pinned against Bio.AlignIO: record ids of unusual files may differ); any other AlignIO format "
+                        "is an error")
     p.add_argument("-N", "--max-nesting", dest="max_nesting", action="store", type=int, default=NESTING_LVL,
                    help="Maximum number of levels to use for nesting. Default: %(default)d")
     p.add_argument("-L", "--min-match-length", dest="min_match_length", action="store", type=int, default=MIN_MATCH_LEN,

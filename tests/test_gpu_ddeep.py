@@ -54,3 +54,71 @@ def test_deep_hierarchical_alignment_against_the_oracle_fixture(fixture, no_tabl
     assert pc.sha(tree) == e["tree_sha256"], "recursion tree differs from the oracle's"
     assert pc.sha(eng.prg_index(0)) == e["prg_index_sha256"]
     assert 5 + 2 * int(eng.site_count[0]) == e["site_num"]
+
+
+def test_hierarchical_alignment_at_config_d_size_properties():
+    """BASELINE.json config D's SIZE with the hierarchical generator (utils/synthetic.synth_rows_deep: 10 000 x 20 000, -N 7 -L 7; the
+    recursion nests to the limit: ~1.2 x 10^5 nodes, ~2.7 x 10^4 KMeans fits, a top problem of 10 000 distinct sequences x 16 384
+    k-mers whose rounds' fits all go out at once — forest.KM_SPEC_PROBLEMS).  No oracle at this size: what holds for ANY recursion
+    tree (tests/prg_walk.py: the site markers nest, every sampled distinct input row is spelt by the PRG — a nested PRG may spell a
+    row along more than one path, as the reference's own PRG of `ddeep` does) and the node table's invariants."""
+    import time
+    from make_prg_amd.backend import HipBackend
+    from make_prg_amd.forest import KIND_CLUSTER, KIND_LEAF, ForestEngine
+    from make_prg_amd.msa import MSA, Record
+    from make_prg_amd.utils.synthetic import synth_rows_deep
+    from tests.prg_walk import _prepare, parse_prg, spellings
+    rows = synth_rows_deep(0, 10_000, 20_000)
+    msa = MSA([Record(r, f"s{i}", f"s{i}") for i, r in enumerate(rows)])
+    eng = ForestEngine(HipBackend(0), 7, 7)
+    eng.load([msa])
+    t0 = time.perf_counter()
+    eng.run_forest()
+    prg = eng.assemble_prgs()[0]
+    wall = time.perf_counter() - t0
+    assert prg is not None and eng.counters.get("speculative_levels", 0) >= 1
+    assert wall < 8.0, f"forest + PRG text took {wall:.1f} s (round 4: 16.6 s, this round: ~3 s)"
+    tree = parse_prg(prg)                 # (raises unless the markers nest and every site number opens and closes once)
+    _prepare(tree)
+    distinct = list(dict.fromkeys(r.decode().replace("-", "") for r in rows))
+    sample = distinct[::max(1, len(distinct) // 120)]
+    paths = [spellings(tree, r) for r in sample]
+    assert min(paths) >= 1, f"{sum(p == 0 for p in paths)} of {len(paths)} sampled rows are not spelt by the PRG"
+    t, n = eng.tab, eng.n_nodes
+    assert n > 50_000 and int(eng.tree_sizes[0]) == n and sorted(eng.node_id.tolist()) == list(range(n))
+    kids = np.concatenate([np.arange(f, f + c) for f, c in zip(t["first_child"], t["n_child"]) if c > 0])
+    assert sorted(kids.tolist()) == list(range(1, n)), "every node but the root is the child of exactly one node"
+    assert (t["n_child"][t["kind"] == KIND_LEAF] == 0).all() and (t["n_child"][t["kind"] != KIND_LEAF] >= 1).all()
+    assert (t["n_child"][t["kind"] == KIND_CLUSTER] >= 2).all()
+    assert 5 <= int(t["level"].max()) < 7          # nests (nearly) down to the limit
+
+
+def test_hierarchical_generator_subsamples_against_oracle():
+    """Row / column subsamples of that alignment (the same generator stream), -N 7: PRG and node count against the oracle at sizes
+    it finishes in seconds — with every level counted as big (threshold 1 byte), so the fits go through the all-rounds-at-once
+    launch of wide workgroups and the many-workgroup statistics that the full-size build takes."""
+    import oracle.from_msa_oracle as orc
+    import make_prg_amd.forest as forest
+    from make_prg_amd.backend import HipBackend
+    from make_prg_amd.forest import ForestEngine
+    from make_prg_amd.msa import load_alignment_text
+    from make_prg_amd.utils.synthetic import synth_rows_deep
+    orc.build_kmeans_lib()
+    rows = synth_rows_deep(0, 10_000, 20_000)
+    texts = []
+    for r0, step, nr, c0, nc in ((0, 40, 200, 0, 1500), (3, 25, 300, 9000, 1200), (5000, 1, 150, 4000, 2500)):
+        texts.append("".join(f">s{i}\n{rows[i][c0:c0 + nc].decode()}\n" for i in range(r0, r0 + step * nr, step)))
+    want = [orc.build_locus_from_text(t, 7, 7) for t in texts]
+    for big_bytes in (forest.KM_BIG_BYTES, 1):
+        saved = forest.KM_BIG_BYTES
+        forest.KM_BIG_BYTES = big_bytes
+        try:
+            eng = ForestEngine(HipBackend(0), 7, 7)
+            eng.load([load_alignment_text(t) for t in texts])
+            eng.run_forest()
+            prgs = eng.assemble_prgs()
+        finally:
+            forest.KM_BIG_BYTES = saved
+        assert [p for p in prgs] == [w[0] for w in want]
+        assert [int(x) for x in eng.tree_sizes] == [w[1].next_node_id for w in want]
+        assert big_bytes != 1 or eng.counters.get("speculative_levels", 0) >= 1

@@ -152,3 +152,22 @@ def test_exported_helper_functions_on_gpu(hip):
         assert check_all(load()) > 300
     finally:
         device.set_backend(None)
+
+
+def test_kmer_dictionary_and_counts_by_many_workgroups(hip, golden_integration, monkeypatch):
+    """mprg_kmer_dictionary_parts / mprg_kmer_counts_parts — a problem's k-mer occurrences shared by many workgroups through global
+    atomics (what the top levels of one deep alignment take) — forced for EVERY level here (KD_PARTS_FROM = 1; every level counted
+    as big, so the counts go through the parts form too), on the device's real atomics: same ids, hence the same column order of
+    every count matrix and the same KMeans sums as the one-workgroup kernels; answers of the oracle and the real reference's goldens."""
+    import make_prg_amd.forest as forest
+    from tests.random_msas import random_cases
+    monkeypatch.setattr(forest, "KD_PARTS_FROM", 1)
+    monkeypatch.setattr(forest, "KM_BIG_BYTES", 1)
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    calls = []
+    orig = hip.call
+    monkeypatch.setattr(hip, "call", lambda name, *a, **k: (calls.append(name), orig(name, *a, **k))[1])
+    pc.check_vs_oracle(hip, random_cases(61, 60), 5, 7)
+    pc.check_vs_oracle(hip, random_cases(62, 30), 3, 3)
+    assert pc.check_integration(hip, golden_integration) >= 30
+    assert calls.count("mprg_kmer_dictionary_parts") >= 3 and calls.count("mprg_kmer_counts_parts") >= 3 and "mprg_kmer_dictionary" not in calls

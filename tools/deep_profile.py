@@ -56,12 +56,15 @@ for p in range(passes):
     if be.profile is not None:
         prof = be.profile_summary()
         rec["device_ms"] = round(sum(v["ms"] for v in prof.values()), 3)
-        rec["entry_points"] = [dict(entry_point=k, ms=round(v["ms"], 3), calls=v["calls"]) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])]
+        rec["entry_points"] = [dict(entry_point=k, ms=round(v["ms"], 3), calls=v["calls"], algorithmic_bytes=float(v["bytes"]),
+                                    achieved_GBps=round(v["bytes"] / max(v["ms"], 1e-9) * 1e-6, 3) if v["bytes"] else None)
+                               for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])]
+        rec["speculative_levels"] = int(eng.counters.get("speculative_levels", 0))
         be.profile = None
     out["passes"].append(rec)
     print(json.dumps({k: v for k, v in rec.items() if k != "entry_points"}), flush=True)
     for e in rec.get("entry_points", [])[:16]:
-        print(f"   {e['entry_point']:34s} {e['ms']:10.3f} ms {e['calls']:5d} calls")
+        print(f"   {e['entry_point']:34s} {e['ms']:10.3f} ms {e['calls']:5d} calls" + (f"  {e['achieved_GBps']:9.1f} GB/s algorithmic" if e["achieved_GBps"] else ""))
 if check:
     # (a nested PRG may spell a row along more than one path: the parity-checked ddeep PRG — identical to the real reference's —
     #  does so for 1 of 219 sampled rows; "at least one path" is the property here, "exactly one" holds for the flat config D)
