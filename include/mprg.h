@@ -55,13 +55,13 @@ int mprg_device_cus(void);
  * upper case; a byte outside ACGT-RYKMSWN sets status[alignment] = 1 (the reference ends such a locus with
  * SequenceCurationError); N is replaced by n_replacement[repl_off + column] (a cell code) where the table gives an offset.
  * msa_table: n_msas x MPRG_I_FIELDS int64 {raw offset, rows, columns, row-major base, transposed base, pitchC, pitchS,
- * replacement offset (-1: keep N), first tile}; an alignment owns ceil(rows/64) * ceil(columns/64) consecutive tiles,
+ * replacement offset (-1: keep N), first tile}; an alignment owns ceil(rows/T) * ceil(columns/T) consecutive tiles, T = MPRG_INGEST_TILE,
  * n_tiles in all.  arena_bytes of `arena` are initialised by the call.
  * mprg_column_residue_counts: for the load-time majority consensus (utils/seq_utils.py:246-290): per column of the listed
  * alignments the number of rows holding each of A C G T R Y K M S W and the first such row.  table: 4 int64 per alignment
  * {raw offset, rows, columns, col_off}; work: n_work x 2 int32 {table row, 256-column tile}; out: 20 int32 per column at
  * 20 * (col_off + c) = count[10], first_row[10] (0x7fffffff: absent).  The seeded random choice stays on the host. */
-enum { MPRG_I_FIELDS = 9 };
+enum { MPRG_I_FIELDS = 9, MPRG_INGEST_TILE = 128 };
 int mprg_ingest(const uint8_t *raw, const int64_t *msa_table, int n_msas, int64_t n_tiles, const uint8_t *n_replacement,
                 uint8_t *arena, int64_t arena_bytes, int32_t *status, void *stream);
 int mprg_column_residue_counts(const uint8_t *raw, const int64_t *table, const int32_t *work, int n_work, int32_t *out,

@@ -24,6 +24,7 @@ ROWS_PER_CHUNK = 512
 PREPARE_LDS_MAX = 156 * 1024         # MPRG_KMEANS_PREPARE_LDS_MAX (include/mprg.h)
 PREPARE_LDS_CLASSES = (12 * 1024, 24 * 1024, 64 * 1024, PREPARE_LDS_MAX)      # one launch per class of LDS need (bytes)
 TILE_COLS = 1024
+INGEST_TILE = 128                    # MPRG_INGEST_TILE (include/mprg.h): rows x columns of an mprg_ingest work item
 IUPAC = {"R": "GA", "Y": "TC", "K": "GT", "M": "AC", "S": "GC", "W": "AT", "A": "A", "C": "C", "G": "G", "T": "T"}
 
 
@@ -153,7 +154,7 @@ class BatchEngine:
             metas.append((rm, cm, pitchC, pitchS, S, C))
             itab[i] = (raw_off, S, C, rm, cm, pitchC, pitchS, -1, tile)
             raw_off += S * C
-            tile += ((S + 63) // 64) * ((C + 63) // 64)
+            tile += ((S + INGEST_TILE - 1) // INGEST_TILE) * ((C + INGEST_TILE - 1) // INGEST_TILE)
         self.meta = metas
         parts = [np.ascontiguousarray(m.data).reshape(-1) for m in msas if m.data.size]
         raw = np.concatenate(parts) if parts else np.zeros(1, np.uint8)

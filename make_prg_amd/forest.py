@@ -1256,7 +1256,8 @@ def load_raw(self: ForestEngine, arena_buf, arena: np.ndarray, raw_off: np.ndarr
     ends = np.cumsum(sz_rm + sz_cm)
     rm = ends - sz_rm - sz_cm
     cm = rm + sz_rm
-    tiles = ((rows + 63) // 64) * ((C0 + 63) // 64)
+    from .engine import INGEST_TILE as T_
+    tiles = ((rows + T_ - 1) // T_) * ((C0 + T_ - 1) // T_)
     itab = np.zeros((max(M, 1), 9), np.int64)
     itab[:M, 0], itab[:M, 1], itab[:M, 2], itab[:M, 3], itab[:M, 4] = raw_off, rows, C0, rm, cm
     itab[:M, 5], itab[:M, 6], itab[:M, 7], itab[:M, 8] = pitchC, pitchS, -1, np.cumsum(tiles) - tiles
