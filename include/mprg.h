@@ -489,6 +489,13 @@ int mprg_forest_assemble_emit(const int64_t *F, void *stream);
  *     MPRG_F_VALS_POS). */
 int mprg_forest_export_count(const int64_t *F, void *stream);
 int mprg_forest_export_fill(const int64_t *F, void *stream);
+/* (f)-2 — the alignments of the exported loci at FOUR BITS per cell, for the update data structure (the reference pickles every
+ * locus's PrgBuilder with its alignment, subcommands/from_msa.py:114-127; the cell codes 0..11 fit a nibble: half the bytes of the
+ * ASCII matrix, which is 96 % of a member).  meta: MPRG_F_META's table (int64 [alignments][6]); row_base: int64 [n_msas + 1], the
+ * first row of every alignment in the launch (total_rows = row_base[n_msas]); row r of alignment m goes to out_off[m] + r *
+ * ceil(columns / 2): cell 2 j in the low nibble of byte j, 15 beside a last odd cell. */
+int mprg_export_alignments(const uint8_t *arena, const int64_t *meta, const int64_t *row_base, const int64_t *out_off, long long n_msas,
+                           long long total_rows, uint8_t *out, void *stream);
 
 /* (f)-1 output encoders, HOST functions (host pointers), one pass over a PRG string as PrgBuilder emits it.
  * reference make_prg/utils/prg_encoder.py:44-91 and make_prg/utils/gfa.py:16-109.

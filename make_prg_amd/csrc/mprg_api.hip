@@ -882,6 +882,12 @@ int mprg_forest_export_fill(const int64_t *F, void *stream) {
 }
 #undef FP
 #undef FHDR
+int mprg_export_alignments(const uint8_t *arena, const int64_t *meta, const int64_t *row_base, const int64_t *out_off, long long n_msas,
+                           long long total_rows, uint8_t *out, void *stream) {
+  if (n_msas <= 0 || total_rows <= 0) return 0;
+  LAUNCH(k_ex_pack_rows, total_rows, 256, stream, arena, meta, row_base, out_off, n_msas, out);
+  return check_launch("k_ex_pack_rows");
+}
 
 // numpy.random.RandomState(seed).random_sample(n): MT19937, init_genrand seeding, 53-bit doubles
 void mprg_random_sample_host(uint32_t seed, int n, double *out) {

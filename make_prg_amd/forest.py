@@ -946,12 +946,13 @@ def _special_leaf_alleles(self: "ForestEngine", rows: np.ndarray) -> Dict[int, L
 
 
 def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool = False, lazy: bool = False, export: bool = False,
-                  ring: int = 0):
+                  ring: int = 0, pack_alignments: bool = False):
     """PRG string of every alignment of the batch (None for loci dropped by the curation policy).  lazy: returns a function
     that waits for the text's copy to the host and returns the list — the copy then overlaps whatever the caller enqueues next
     (as_bytes views stay valid until the second following assemble_prgs of this engine's backend).
     want_index: self.prg_index_entries(i) afterwards.  export: self.exported = the trees as per-locus slices of three arrays
     (records, rows, PRG index: mprg_forest_export_* in include/mprg.h) for the update data structure.
+    pack_alignments (with export): self.exported also holds every alignment at four bits per cell (mprg_export_alignments).
     ring: which set of pinned buffers the copies cycle through (backend.download_async groups 4 * ring ..): a caller that builds
     a side batch on a backend whose main ring is in use by a pipeline (pipeline.py: the object path of a chunk) takes its own.
     Device (mprg_forest_assemble_*): preorder ranks and site numbers, text lengths bottom-up, text offsets top-down over the
@@ -1010,13 +1011,24 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool =
         be.call("mprg_emit_alleles", be.ptr(self.d_arena), be.ptr(d_jobs), n_jobs, be.ptr(d_out), be.stream,
                 work=float(2 * total_chars))
         self.counters["launches"] += 1
-    d_rec = d_rows = None
-    n_ex_rows = 0
+    d_rec = d_rows = d_aln = None
+    n_ex_rows = aln_bytes = 0
     if export:
         n_ex_rows = int(self._step("export_count", n_hdr=1)[0])
         d_rec, d_rows = be.empty(32 * n), be.empty(4 * max(n_ex_rows, 1))
         self._set(EX_RECORDS=d_rec, EX_ROWS=d_rows)
         self._step("export_fill")
+        if pack_alignments:          # the loci's alignments at four bits per cell (mprg_export_alignments), for the update_DS members
+            S_, C_ = self.meta_arr[:, 4], self.meta_arr[:, 5]
+            row_base = np.concatenate([[0], np.cumsum(S_)]).astype(np.int64)
+            sizes = S_ * ((C_ + 1) // 2)
+            aln_off = (np.cumsum(sizes) - sizes).astype(np.int64)
+            aln_bytes = int(sizes.sum())
+            d_aln = be.empty(max(aln_bytes, 16))
+            d_rb, d_ao = be.upload(row_base), be.upload(aln_off)
+            be.call("mprg_export_alignments", be.ptr(self.d_arena), be.ptr(self.d_meta), be.ptr(d_rb), be.ptr(d_ao), M, int(row_base[-1]),
+                    be.ptr(d_aln), be.stream, work=1.5 * float((S_ * C_).sum()))
+            self.counters["launches"] += 1
     # small copies before the big asynchronous one (a copy queued behind 2.5 GB on the DMA engine waits for it).
     # per alignment: start of its PRG in the batch text, first allele job / index entry, first node of its preorder run,
     # first entry of its exported rows
@@ -1050,6 +1062,10 @@ def assemble_prgs(self: ForestEngine, want_index: bool = False, as_bytes: bool =
         self.exported = dict(records=rec_host.view(np.int32).reshape(-1, 8), rows=rows_host.view(np.int32), node_bounds=node_bounds,
                              row_bounds=bounds(np.where(self.root_of >= 0, mb[:, 3], -1), n_ex_rows),
                              index=self._index[0], index_bounds=self._index[1])
+        if d_aln is not None:
+            aln_host, w3 = be.download_async(d_aln, aln_bytes, group=8 + ring)
+            waits.append(w3)
+            self.exported.update(alignments=aln_host, alignment_off=aln_off, alignment_bytes=sizes.astype(np.int64))
     if host_leaf:
         _ = self.asm, self.tab
     buf, wait = be.download_async(d_out, total_chars, group=4 * ring)

@@ -37,12 +37,15 @@ TRACE = os.environ.get("MPRG_PIPELINE_TRACE", "") not in ("", "0")
 # threads that write one container side by side: buffered writes to ONE file take the inode's lock in turn (tools/write_probe.py:
 # 1 / 4 / 16 threads on a file all reach ~10 GB/s), so more than two only spin on that lock
 WRITE_THREADS = int(os.environ.get("MPRG_WRITE_THREADS", "2"))
+# update_DS members keep their locus's alignment at four bits per cell, packed by the device (update_ds.py "nib4"); 0: ASCII from the parser's arena
+PACK_ALIGNMENTS = os.environ.get("MPRG_PACK_ALIGNMENTS", "1") != "0"
+TWO_ENGINES = os.environ.get("MPRG_PIPELINE_ENGINES", "2") != "1"          # chunks in turn on two backends (streams): see run_pipeline
 
 
 def _trace(msg):
     if TRACE:
         import sys
-        sys.stderr.write("[pipeline] " + msg + "\n")
+        sys.stderr.write(f"[pipeline] +{since_process_start():6.3f} s  " + msg + "\n")
 
 
 def since_process_start() -> float:
@@ -218,25 +221,57 @@ def run_pipeline(files: List[Path], options, backend, segment: bool = False):
     be = backend() if callable(backend) else backend
     _trace(f"device ready {since_process_start():.2f} s after the process started") if TRACE else None
     be.async_depth = DEPTH
+    # two backends (streams, pinned rings) take the chunks in turn: chunk i + 1 is uploaded and its forest enqueued BEFORE the host
+    # waits for chunk i, lays its text out and hands it to the output stage — the device works on one chunk while the host finishes
+    # the other (a backend object handed in — tests — builds chunk by chunk)
+    bes = [be]
+    if TWO_ENGINES and len(chunks) > 1 and hasattr(be, "clone"):
+        bes.append(be.clone())          # (its own streams and device buffers; this backend's pinned host memory)
+    closer = ThreadPoolExecutor(1)
+    release = lambda h: closer.submit(lib.mprg_ingest_close_host, h)
+    pending = None
     try:
         while True:
+            if TRACE:
+                import time as _t
+                t_q = _t.perf_counter()
             item = q_in.get()
             if item is None or errors:
                 break
             ci, chunk, h, info = item
+            if TRACE:
+                import time as _t
+                t_w = _t.perf_counter()
             slot_free[ci % DEPTH].acquire()
+            if TRACE:
+                _trace(f"chunk {ci}: waited {1e3 * (t_w - t_q):.0f} ms for the parser, {1e3 * (_t.perf_counter() - t_w):.0f} ms for its buffers")
             if errors:
                 break
-            q_out.put(_build_chunk(lib, be, options, threads, ci, chunk, h, info))
+            b_ = bes[ci % len(bes)]
+            if getattr(b_, "plan_donor", None) is None:          # (the other backend's last chunk sizes this one's first)
+                b_.plan_donor = next((x.plan_donor for x in bes if getattr(x, "plan_donor", None) is not None), None)
+            st = _build_begin(lib, b_, options, threads, ci, chunk, h, info)
+            if len(bes) == 1:
+                q_out.put(_build_end(lib, options, threads, st, release))
+                continue
+            if pending is not None:
+                q_out.put(_build_end(lib, options, threads, pending, release))
+            pending = st
+        if pending is not None and not errors:
+            q_out.put(_build_end(lib, options, threads, pending, release))
+            pending = None
     finally:
+        closer.shutdown(wait=True)
         q_out.put(None)
         t_out.join()
         writers.shutdown(wait=True)
     if errors:
         raise errors[0]
     out.close()
-    if callable(backend) and hasattr(be, "close") and os.environ.get("MPRG_FAST_EXIT", "1") == "0":
-        be.close()          # a backend made here is released here (the command line leaves through os._exit instead: un-pinning GBs is slow)
+    if os.environ.get("MPRG_FAST_EXIT", "1") == "0":          # (the command line leaves through os._exit instead: un-pinning GBs is slow)
+        for b_ in reversed(bes[1:] + ([be] if callable(backend) else [])):          # clones first, then a backend made here
+            if hasattr(b_, "close"):
+                b_.close()
     _trace(f"outputs closed {since_process_start():.2f} s after the process started") if TRACE else None
     return segment_index(out) if segment else out.n
 
@@ -250,9 +285,11 @@ def segment_index(out: "_Outputs") -> dict:
     return idx
 
 
-def _build_chunk(lib, be, options, threads, ci, chunk, h, info):
-    """Device stage of one chunk: fast files through the arena, the rest through the object path.  Returns what the output
-    stage needs."""
+def _build_begin(lib, be, options, threads, ci, chunk, h, info):
+    """Device stage of one chunk, first half: the fast files parsed into the chunk's pinned arena, ONE upload, device ingest, and the
+    whole recursion forest ENQUEUED (forest.forest_enqueue: from the previous chunk's totals without a host wait; the first chunk
+    of a run takes the per-step host here).  _build_end() completes it: the two halves of successive chunks are interleaved on two
+    backends (streams), so a chunk's kernels run while the host lays out the one before."""
     from .subcommands import from_msa as drv
     import time
     t_start = time.perf_counter()
@@ -269,6 +306,7 @@ def _build_chunk(lib, be, options, threads, ci, chunk, h, info):
     fi = np.nonzero(fast)[0]
     slow = [i for i in range(len(chunk)) if not fast[i]]
     res = dict(ci=ci, chunk=chunk, fi=fi, slow_records={})
+    st = dict(res=res, be=be, slow=slow, h=h, t_start=t_start, eng=None)
     if len(fi):
         sizes = rows[fi] * cols[fi]
         raw_off = np.cumsum(sizes) - sizes
@@ -286,17 +324,35 @@ def _build_chunk(lib, be, options, threads, ci, chunk, h, info):
         t_fill = time.perf_counter()
         eng = ForestEngine(be, options.max_nesting, options.min_match_length)
         eng.load_raw(arena_buf, arena, raw_off, rows[fi], cols[fi], has_n=(flags[fi] & 2) != 0, ids_of=ids_of)
-        eng.run_forest()
-        t_load = time.perf_counter()
-        fin = eng.assemble_prgs(as_bytes=True, lazy=True, export=ot.prg)
-        _trace(f"chunk {ci}: fill {1e3 * (t_fill - t_start):.0f} ms, load + forest {1e3 * (t_load - t_fill):.0f} ms, "
-               f"assemble {1e3 * (time.perf_counter() - t_load):.0f} ms ({len(fi)} alignments)")
-        res.update(eng=eng, fin=fin, arena=arena, raw_off=raw_off, rows=rows[fi], cols=cols[fi], titles=titles, t_off=t_off,
+        eng.forest_enqueue()
+        st.update(eng=eng, t_fill=t_fill, t_enq=time.perf_counter())
+        res.update(eng=eng, arena=arena, raw_off=raw_off, rows=rows[fi], cols=cols[fi], titles=titles, t_off=t_off,
                    tbytes=tbytes[fi], site_count=None)
-    if slow:          # gzip / non-ASCII / duplicate ids / other formats: the object path, inside this chunk
-        loaded = [drv._load_one((chunk[i], options.alignment_format)) for i in slow]
+    return st
+
+
+def _build_end(lib, options, threads, st, release):
+    """Second half: waits for the chunk's forest, lays the PRG text and the tree export out and starts their copies to pinned
+    memory; the files the native parser left alone take the object path here.  Returns what the output stage needs.
+    release(h): gives the chunk's parser state back (off this thread: un-mapping ~300 MB takes 4-16 ms)."""
+    from .subcommands import from_msa as drv
+    import time
+    res, be, ot = st["res"], st["be"], options.output_type
+    ci, chunk = res["ci"], res["chunk"]
+    t0 = time.perf_counter()
+    if st["eng"] is not None:
+        eng = st["eng"]
+        eng.forest_finish()
+        t_load = time.perf_counter()
+        fin = eng.assemble_prgs(as_bytes=True, lazy=True, export=ot.prg, pack_alignments=ot.prg and PACK_ALIGNMENTS)
+        _trace(f"chunk {ci}: fill {1e3 * (st['t_fill'] - st['t_start']):.0f} ms, load + enqueue {1e3 * (st['t_enq'] - st['t_fill']):.0f} ms, "
+               f"forest done after {1e3 * (t_load - st['t_enq']):.0f} ms (waited {1e3 * (t_load - t0):.0f} ms), "
+               f"assemble {1e3 * (time.perf_counter() - t_load):.0f} ms ({len(res['fi'])} alignments)")
+        res.update(fin=fin)
+    if st["slow"]:          # gzip / non-ASCII / duplicate ids / other formats: the object path, inside this chunk
+        loaded = [drv._load_one((chunk[i], options.alignment_format)) for i in st["slow"]]
         msas, loci = [], []
-        for i, m in zip(slow, loaded):
+        for i, m in zip(st["slow"], loaded):
             locus = remove_known_input_extensions(chunk[i].name)
             if isinstance(m, ValueError):
                 if "No records found in handle" in str(m.args[0]):
@@ -307,8 +363,8 @@ def _build_chunk(lib, be, options, threads, ci, chunk, h, info):
         # (its copies cycle through pinned buffers of their OWN: the main ring holds the text / tree export of this chunk and of the
         #  two before it, which the output stage and the writers may still be reading)
         drv._build_batch(msas, loci, options, be, res["slow_records"], ring=1)
-    if h is not None:
-        lib.mprg_ingest_close_host(h)
+    if st["h"] is not None:
+        release(st["h"])
     return (res,)
 
 
@@ -448,14 +504,19 @@ def _write_chunk(lib, out: _Outputs, options, threads, res):
             extra_ix = [np.asarray(eng._host_index[j], np.int32).tobytes() if j in eng._host_index else b"" for j in okj.tolist()] \
                 if eng._host_index else None
             fmt, N_, L_ = options.alignment_format, options.max_nesting, options.min_match_length
-            heads = [member_header(nm, fmt, N_, L_, a, 5 + 2 * b, c, d, e, a, f, g + (len(extra_ix[q]) // 12 if extra_ix else 0))
+            packed = "alignments" in ex
+            heads = [member_header(nm, fmt, N_, L_, a, 5 + 2 * b, c, d, e, a, f, g + (len(extra_ix[q]) // 12 if extra_ix else 0),
+                                   enc="nib4" if packed else None)
                      for q, (nm, a, b, c, d, e, f, g) in enumerate(zip(ok_names, n_nodes.tolist(), site.tolist(), S.tolist(), C.tolist(),
                                                                         tb.tolist(), n_rows.tolist(), n_ix.tolist()))]
             blob = np.frombuffer(b"".join(heads), np.uint8)
             hl = np.fromiter((len(h) for h in heads), np.int64, n_m)
             keep += [blob, res["titles"]]
             addr[:, 0], ln[:, 0] = blob.ctypes.data + np.cumsum(hl) - hl, hl
-            addr[:, 1], ln[:, 1] = res["arena"].ctypes.data + ro, S * C
+            if packed:          # the alignment at four bits per cell, packed by the device (mprg_export_alignments)
+                addr[:, 1], ln[:, 1] = ex["alignments"].ctypes.data + ex["alignment_off"][okj], ex["alignment_bytes"][okj]
+            else:
+                addr[:, 1], ln[:, 1] = res["arena"].ctypes.data + ro, S * C
             addr[:, 2], ln[:, 2] = res["titles"].ctypes.data + to, tb
             addr[:, 3], ln[:, 3] = ex["records"].ctypes.data + 32 * nb[okj], 32 * n_nodes
             addr[:, 4], ln[:, 4] = ex["rows"].ctypes.data + 4 * rb[okj], 4 * n_rows

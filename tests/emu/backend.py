@@ -45,6 +45,11 @@ class EmuBackend(_Base):
         self.stream = None
         self.n_cus = 1
 
+    def clone(self):
+        """A second backend over the same library (pipeline.py interleaves two engines on a backend and its clone)."""
+        import copy
+        return copy.copy(self)
+
     def empty(self, nbytes):
         return np.full(max(int(nbytes), 16), 0xA5, np.uint8)   # poison: catches reads of unwritten scratch
 
