@@ -45,8 +45,8 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 DIGESTS = os.path.join(ROOT, "tests", "golden", "config_c_digests.bin")
 KERNEL_OF = {"mprg_kmeans_restarts": "k_kmeans_restart", "mprg_kmeans_fit": "k_kmeans_restart_select (persistent form: k_kmeans_fit)",
              "mprg_kmeans_fit_small": "k_kmeans_restart_select_small", "mprg_kmeans_fit_split": "k_kmeans_restart_one + k_kmeans_select_list", "mprg_kmeans_fit_wave": "k_kmeans_fit_wave",
-             "mprg_column_masks": "k_column_masks", "mprg_partition": "k_partition (+ k_partition_fused, k_gap_runs, k_pack_scan, k_pack_copy)",
-             "mprg_ungap_dedupe": "k_ungap_dedupe (+ k_ungap_hash, k_ungap_hash_u)", "mprg_emit_alleles": "k_emit_alleles",
+             "mprg_column_masks": "k_column_masks", "mprg_partition": "k_partition (+ k_partition_wave, k_partition_fused, k_gap_runs, k_pack_scan, k_pack_copy)",
+             "mprg_ungap_dedupe": "k_ungap_dedupe (+ k_dedupe_wave, k_ungap_hash, k_ungap_hash_u)", "mprg_emit_alleles": "k_emit_alleles",
              "mprg_cluster_loop[general]": "k_cluster_loop", "mprg_cluster_loop[small]": "k_cluster_loop_small",
              "mprg_cluster_further": "k_cluster_majority + k_cluster_hamming",
              "mprg_kmeans_prepare": "k_kmeans_prepare_lds (+ k_kmeans_prepare, k_kmeans_prepare_tables)"}
@@ -388,7 +388,7 @@ def main():
         except Exception:
             avail_kib = 64 << 20
         W = max(1, min(W, max(1, (ncpu - 1) // max(world, 1)), int(avail_kib / (4 << 20) / 4 / max(world, 1))))
-    # The shape of a rank's host side follows its shard (measured on MI355X, profiles/r04/host_shapes.md):
+    # The shape of a rank's host side follows its shard (measured on MI355X, profiles/r04/host_shapes.md, re-measured in round 5: profiles/r05/host_shapes.txt):
     #   a small shard (what a rank of an 8-GPU run sees: 3 750 alignments per step) is built best by ONE worker process whose single
     #   host thread feeds TWO engines (sub-batches on streams of their own; forests enqueued without waits from the previous pass's
     #   totals, forest.forest_enqueue) with the clustering loop's general and small forms side by side on a side stream:
@@ -706,14 +706,14 @@ def main():
         # exactly these kernel sources; otherwise null
         traffic = traffic_note = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r04", "pmc_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r05", "pmc_summary.json")))
             if pm.get("source_digest") == source_digest():
                 # the PMC passes profile a different batch (8192 alignments in one process), so their bytes per launch are
                 # not this pass's: what carries over is HBM bytes / algorithmic bytes of the entry point, measured there
                 ratio = pm["entry_points"][name]["traffic_over_algorithmic"]
                 traffic = round(ratio * top["algorithmic_bytes_per_launch"], 1)
                 traffic_note = (f"{ratio} x algorithmic bytes: (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes of {name} in the PMC "
-                                f"passes of the same sources (profiles/r04/pmc_summary.json, source_digest {pm['source_digest']})")
+                                f"passes of the same sources (profiles/r05/pmc_summary.json, source_digest {pm['source_digest']})")
         except Exception:
             pass
         roof = dict(bound="hbm", kernel=top["kernel"], entry_point=name, achieved=top["achieved_GBps"] or 0.0,
