@@ -103,6 +103,7 @@ _CAP_COLS = {(0, 0): (0, 14), (0, 1): (0, 0), (0, 3): (0, 14), (0, 4): (0, 14), 
              (5, 0): (3, 0), (5, 1): (5, 0), (5, 2): (5, 0)}
 PLAN_HEAD = float(os.environ.get("MPRG_PLAN_HEAD", "1.35"))          # headroom of a predicted total ...
 PLAN_SPREAD = float(os.environ.get("MPRG_PLAN_SPREAD", "24"))        # ... + this / sqrt(items behind it)
+PLAN_SLACK_LEVELS = int(os.environ.get("MPRG_PLAN_SLACK_LEVELS", "0"))
 PLAN_FLOOR = float(os.environ.get("MPRG_PLAN_FLOOR", "8"))           # room for this many more items of the donor's largest average size
 PLAN_TRACE = os.environ.get("MPRG_PLAN_TRACE", "") not in ("", "0")
 DONOR_MIN_ROOTS = int(os.environ.get("MPRG_DONOR_MIN_ROOTS", "16"))  # a forest of fewer alignments is nobody's donor
@@ -336,7 +337,7 @@ class ForestEngine(BatchEngine):
         """Capacities of a batch seen for the first time, from the totals of ANOTHER batch: every total scaled by the ratio of the
         batches' cells, times a headroom that grows as the number of items behind the total shrinks (a total over n items is
         predicted to ~ 1 / sqrt(n)), plus room for PLAN_FLOOR more items of the largest average size any level of the donor saw.
-        One level more than the donor had, with the floor's room only.  The chain of frontiers is made consistent (a level's
+        The chain of frontiers is made consistent (a level's
         frontier holds what the level before may create), the LDS classes are launched with their upper bounds."""
         if donor.get("settings") != (self.max_nesting, self.L):
             return None
@@ -359,7 +360,9 @@ class ForestEngine(BatchEngine):
 
         levels, n_front = [], len(ok)
         n_nodes, pool = len(ok), 0
-        for lv in list(src) + [None]:
+        # (PLAN_SLACK_LEVELS levels more than the donor had, with the floor's room only: 0 — a batch that nests deeper than its donor
+        #  stops at the level that must find an empty frontier and is enqueued again from there; every level costs ~60 launches)
+        for lv in list(src) + [None] * PLAN_SLACK_LEVELS:
             out = {s_: np.zeros(HDR, np.int64) for s_ in range(6)}
             for (st, c) in _CAP_COLS:
                 out[st][c] = cap_of(lv, st, c)
