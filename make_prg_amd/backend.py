@@ -7,6 +7,11 @@ explicitly by tests and never imported from here.)
 """
 import ctypes
 import os
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue run one after the other.
+# A worker here drives two engines, each with a compute, a side and a copy stream: with eight queues a 3 750-alignment pass took
+# 49.7 ms against 50.9 (first pass, profiles/r05/shards/), four engines 50.5 against 67.7.  Read by the runtime when it starts: set
+# before the library (or torch) is loaded; an explicit setting of the caller's wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from typing import Optional
 
 import numpy as np
