@@ -54,6 +54,11 @@ for p in range(passes):
                prg_chars=len(prg), plan_misses=int(eng.counters.get("plan_misses", 0)),
                host="per-step host" if eng.counters.get("syncs", 0) > 3 * len(eng.levels) else "enqueued from the plan")
     if be.profile is not None:
+        if os.environ.get("MPRG_PROFILE_ALL_LAUNCHES"):          # per launch: the wide fits of every level
+            for name in ("mprg_kmeans_fit_wide", "mprg_kmeans_prepare_big", "mprg_cluster_further"):
+                evs = be.profile.get(name, [])
+                be.synchronize()
+                print(f"  per launch {name}: " + " ".join(f"{a.elapsed_time(b):.1f}" for a, b, _ in evs))
         prof = be.profile_summary()
         rec["device_ms"] = round(sum(v["ms"] for v in prof.values()), 3)
         rec["entry_points"] = [dict(entry_point=k, ms=round(v["ms"], 3), calls=v["calls"], algorithmic_bytes=float(v["bytes"]),
