@@ -83,8 +83,8 @@ int mprg_compact_columns(const uint8_t *arena, const int64_t *views, const int32
                          int rows_per_chunk, const uint32_t *mask, uint8_t *out, const int64_t *out_off, int32_t *kept, void *stream);
 
 /* A3-A6 — from_msa/interval_partition.py:81-252 (IntervalPartitioner) with utils/seq_utils.py:37-42
- * (has_empty_sequence) and the <2-sequences test of :187-217.  Gap runs: one workgroup per (view, 256-row chunk, 2 048-column
- * segment) — work_rows: n x 2 int32 {view, segment * row chunks of the view + row chunk}, ceil(rows / 256) * ceil(columns / 2048) items
+ * (has_empty_sequence) and the <2-sequences test of :187-217.  Gap runs: one workgroup per (view, 256-row chunk, 512-column
+ * segment) — work_rows: n x 2 int32 {view, segment * row chunks of the view + row chunk}, ceil(rows / 256) * ceil(columns / 512) items
  * per view —; the interval scan itself: one workgroup per view.
  * in:  mask (from mprg_column_masks), min_match_length.
  * scratch: maxrun uint32[total_cols] (zeroed), stack int32[4*total_cols], ivflag int32[total_cols*2] (zeroed)
@@ -108,7 +108,7 @@ int mprg_partition(const uint8_t *arena, const int64_t *views, const int32_t *ro
 
 /* A9a/A13/A16 — from_msa/cluster_sequences.py:220-233 (ungap, group identical rows in first-appearance order),
  * utils/seq_utils.py:58-70 (unique gapped / ungapped counts).  Ungap + hash: one workgroup per (view, row chunk) — work_rows:
- * n x 2 int32 {view, chunk}; a chunk is 256 rows, 32 for a view of more than 4 096 columns —, one wavefront per row; grouping: one
+ * n x 2 int32 {view, chunk}; a chunk is 256 rows, 8 for a view of more than 4 096 columns —, one wavefront per row; grouping: one
  * workgroup per view, after a scan over the same work items for the views of more than 512 rows.
  * views[AUX0] = byte offset (a multiple of 16) of this view's region in `ucodes`: n_rows * upitch bytes, upitch =
  * round_up(n_cols, 16); ungapped codes are stored ROW-MAJOR: character j of row position i at i*upitch + j.
@@ -256,7 +256,8 @@ void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
 /* A10 — cluster_sequences.py:59-111 (majority string, Hamming distance, one-reference-like test, cluster_further).
  * Two launches: majority strings per (problem, column tile) — work_cols: n x 2 int32 {problem, tile}; a tile is 256 columns, 32 for a
  * problem whose view has more than 1 024 rows (MPRG_CF_TILE / _TILE_BIG / _ROWS below) — then
- * Hamming distances per (problem, 256-row chunk) — work_rows: n x 2 int32 {problem, chunk}.
+ * Hamming distances per (problem, row chunk) — work_rows: n x 2 int32 {problem, chunk}; a chunk is 256 rows, 16 for a problem of
+ * 512 columns or more and more than 1 024 rows (MPRG_CF_WIDE / _ROWS / _ROWS_WIDE).
  * A row takes part if d_of_row >= 0; its cluster is labels[prob[LABEL_OFF] + d_of_row] (labels == NULL: a single
  * cluster).  Ties in the per-column majority go to the symbol seen first in the order in which the reference enumerates
  * the cluster's rows (distinct sequence, then row).  If `assign` is given the labels of these problems are also copied
@@ -268,12 +269,20 @@ void mprg_random_sample_host(uint32_t seed, int n, double *out_host);
  * read a view as one contiguous block instead of a narrow slice of every alignment row.
  * kinfo (optional, the fit descriptors of that round, problem p = fit p): a problem whose descriptor says k = 0 sat the round out
  * (mprg_forest_kloop_advance) and is skipped here too.  In mprg_kmeans_fit (slot_ws == NULL) a fit with k = 0 returns at once. */
-enum { MPRG_CF_TILE = 256, MPRG_CF_TILE_BIG = 32, MPRG_CF_ROWS = 1024 };
+enum { MPRG_CF_TILE = 256, MPRG_CF_TILE_BIG = 32, MPRG_CF_ROWS = 1024, MPRG_CF_WIDE = 512, MPRG_CF_ROWS_WIDE = 16 };
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
                          int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                          const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
                          int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, const int32_t *kinfo,
                          void *stream);
+/* mprg_cluster_further given the caller's bound on the rows of a problem's view (max_rows; 0: none known, as mprg_cluster_further):
+ * problems of more than MPRG_CF_ROWS rows get their majority strings from a launch of wide workgroups over the same column tiles
+ * (their slices of rows share the tile's counters in LDS), which is left out when the bound says no problem is that tall. */
+int mprg_cluster_further_bounded(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
+                                 int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
+                                 const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
+                                 int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, const int32_t *kinfo,
+                                 long long max_rows, void *stream);
 
 /* A11 + A10 + A12 as ONE launch per workgroup form — cluster_sequences.py:256-274, the whole loop
  *     while cluster_further(...): num_clusters += 1; KMeans(num_clusters).fit(X).predict(X); accept / revert

@@ -51,6 +51,8 @@ SIGNATURES = {
     "mprg_kmeans_fit_small": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7),
     "mprg_kmeans_select": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 5),
     "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int] + [c_void_p] * 6),
+    "mprg_cluster_further_bounded": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int] + [c_void_p] * 5
+                                     + [ctypes.c_longlong, c_void_p]),
     "mprg_cluster_loop": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 14 + [c_int, c_void_p]),
     "mprg_split_children": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 7),
     "mprg_leaf_jobs": (c_int, [c_void_p, c_int64] + [c_void_p] * 6),

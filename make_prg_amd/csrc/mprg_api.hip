@@ -388,7 +388,7 @@ static int d_cluster_further(const uint8_t *arena, const int64_t *views, const i
                              int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                              const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
                              int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, const int32_t *kinfo,
-                             void *stream, DsCount dc_cols, DsCount dc_rows, DsCount dc_probs);
+                             void *stream, DsCount dc_cols, DsCount dc_rows, DsCount dc_probs, long long max_rows = 0);
 int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
                          int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                          const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
@@ -397,11 +397,19 @@ int mprg_cluster_further(const uint8_t *arena, const int64_t *views, const int32
   return d_cluster_further(arena, views, rowidx, prob, n_probs, k, d_of_row, labels, assign, work_cols, n_work_cols, work_rows, n_work_rows,
                            scratch, out_further, km_info, gcodes, kinfo, stream, DS_HOST, DS_HOST, DS_HOST);
 }
+int mprg_cluster_further_bounded(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
+                                 int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
+                                 const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
+                                 int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, const int32_t *kinfo,
+                                 long long max_rows, void *stream) {
+  return d_cluster_further(arena, views, rowidx, prob, n_probs, k, d_of_row, labels, assign, work_cols, n_work_cols, work_rows, n_work_rows,
+                           scratch, out_further, km_info, gcodes, kinfo, stream, DS_HOST, DS_HOST, DS_HOST, max_rows);
+}
 static int d_cluster_further(const uint8_t *arena, const int64_t *views, const int32_t *rowidx, const int64_t *prob,
                              int n_probs, int k, const int32_t *d_of_row, const int32_t *labels, int32_t *assign,
                              const int32_t *work_cols, int n_work_cols, const int32_t *work_rows, int n_work_rows,
                              int32_t *scratch, int32_t *out_further, const double *km_info, const uint8_t *gcodes, const int32_t *kinfo,
-                             void *stream, DsCount dc_cols, DsCount dc_rows, DsCount dc_probs) {
+                             void *stream, DsCount dc_cols, DsCount dc_rows, DsCount dc_probs, long long max_rows) {
   if (n_probs <= 0) return 0;
   if (k < 1 || k > KM_KMAX) return fail("mprg_cluster_further: k out of range");
   if (hipMemsetAsync(out_further, 0, sizeof(int32_t) * n_probs, (hipStream_t)stream) != hipSuccess) return fail("memset");
@@ -409,8 +417,13 @@ static int d_cluster_further(const uint8_t *arena, const int64_t *views, const i
   const int one = (g_cf_one && gcodes) ? 1 : 0;
   if (one) LAUNCH(k_cluster_further_one, n_probs, CFO_THREADS, stream, views, prob, n_probs, k, d_of_row, labels, assign, km_info, out_further, gcodes,
                   kinfo, dc_probs);
+  // problems of more than CF_ROWS rows: their majority strings by wide workgroups in a launch of their own over the same work items
+  // (left out when the caller's bound on the rows of a view says there is none: max_rows, 0 = none known)
+  const int big = (max_rows <= 0 || max_rows > CF_ROWS) ? 1 : 0;
   LAUNCH(k_cluster_majority, n_work_cols, CF_THREADS, stream, arena, views, rowidx, prob, work_cols, k, d_of_row, labels,
          assign, km_info, scratch, gcodes, kinfo, one, dc_cols);
+  if (big) LAUNCH(k_cluster_majority_big, n_work_cols, CFB_THREADS, stream, arena, views, rowidx, prob, work_cols, k, d_of_row, labels,
+                  scratch, gcodes, kinfo, dc_cols);
   LAUNCH(k_cluster_hamming, n_work_rows, CF_TILE, stream, arena, views, rowidx, prob, work_rows, d_of_row, labels,
          (const int32_t *)scratch, out_further, gcodes, kinfo, one ? k : 0, dc_rows);
   return check_launch("k_cluster_further");
@@ -726,7 +739,7 @@ int mprg_forest_level(const int64_t *F, void *stream) {
       if (d_cluster_further(arena, FP(const int64_t, MPRG_F_SUB), pool, FP(const int64_t, MPRG_F_T1), (int)cap_pq, 1, FP(const int32_t, MPRG_F_D_OF_ROW),
                             nullptr, nullptr, FP(const int32_t, MPRG_F_WORK_COLS), (int)C[MPRG_CAP_WC], FP(const int32_t, MPRG_F_WORK_ROWS),
                             (int)C[MPRG_CAP_WR], FP(int32_t, MPRG_F_CF_SCRATCH), FP(int32_t, MPRG_F_FURTHER), nullptr, FP(const uint8_t, MPRG_F_GCODES),
-                            nullptr, stream, slot(b2 + 1), slot(b2 + 2), slot(b2 + 0)) != 0) return -1;
+                            nullptr, stream, slot(b2 + 1), slot(b2 + 2), slot(b2 + 0), F[MPRG_F_MAX_ROWS]) != 0) return -1;
       // ---- S4 the clustering problems, their k-mer dictionaries
       int64_t *b3 = blk(MPRG_STEP_PROBLEMS);
       const long long cap_p = F[MPRG_F_P];

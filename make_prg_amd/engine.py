@@ -249,15 +249,15 @@ class BatchEngine:
 
     @classmethod
     def _gap_run_work(cls, tab: np.ndarray) -> np.ndarray:
-        """Work items of mprg_partition's gap-run launch: (256-row chunk, 2 048-column segment) pairs of every view (gr_items,
+        """Work items of mprg_partition's gap-run launch: (256-row chunk, 512-column segment) pairs of every view (gr_items,
         csrc/k_partition.inc)."""
-        return cls._items(((tab[:, 5] + 255) // 256) * ((tab[:, 7] + 2047) // 2048))
+        return cls._items(((tab[:, 5] + 255) // 256) * ((tab[:, 7] + 511) // 512))
 
     @classmethod
     def _dedupe_work(cls, tab: np.ndarray) -> np.ndarray:
-        """Work items of mprg_ungap_dedupe: row chunks of 256 rows, 32 for a view of more than 4 096 columns (ug_chunks,
+        """Work items of mprg_ungap_dedupe: row chunks of 256 rows, 8 for a view of more than 4 096 columns (ug_chunks,
         csrc/k_rows.inc)."""
-        chunk = np.where(tab[:, 7] > 4096, 32, 256)
+        chunk = np.where(tab[:, 7] > 4096, 8, 256)
         return cls._items((tab[:, 5] + chunk - 1) // chunk)
 
     # ------------------------------------------------------------------------------------------------ main entry
@@ -414,7 +414,8 @@ class BatchEngine:
 
         # (column tiles: 256 columns, 32 for a problem of more than 1 024 rows — cf_col_tiles, csrc/k_cluster.inc)
         tile = np.where(sub[views, 5] > 1024, 32, 256)
-        return items((sub[views, 7] + tile - 1) // tile), items((sub[views, 5] + 255) // 256), float((sub[views, 5] * sub[views, 7]).sum())
+        chunk = np.where((sub[views, 7] >= 512) & (sub[views, 5] > 1024), 16, 256)          # (row chunks: 256 rows, 16 for a problem of >= 512 columns and > 1 024 rows — cf_row_chunks)
+        return items((sub[views, 7] + tile - 1) // tile), items((sub[views, 5] + chunk - 1) // chunk), float((sub[views, 5] * sub[views, 7]).sum())
 
     def _cluster_further_plan(self, d_sub, d_rowidx, sub, act_tab, k, d_dor, d_labels, d_assign, d_scratch, d_further, staged=None,
                               d_gcodes=None):

@@ -308,6 +308,7 @@ class ForestEngine(BatchEngine):
                   FUSED_ENABLED=int(FUSED_VIEWS), N_INIT=N_INIT, HDR=self.d_hdr, HDR_HOST=self._hdr_buf)
         for k_, o_ in uoff.items():
             self.F[FI["UOFF"] + k_] = o_
+        self.F[FI["MAX_ROWS"]] = int(self.meta_arr[ok, 4].max()) if len(ok) else 1          # no view has more rows than its root
         self._d_uni, self._uoff = d_uni, uoff
 
     def _forest_end(self, check_failed: bool):
@@ -416,7 +417,6 @@ class ForestEngine(BatchEngine):
         self._set(DS=d_ds, UNIFORMS=self._d_uni, LOOP_FORMS=(1 | 8 | 2 | 4) if small else 1)
         self.F[FI["SIDE_STREAM"]] = be.side_ptr(0) if (small and KM_SIDE_STREAMS and be.n_side_streams >= 1 and be.side_ptr(0) != be.stream) else 0
         self.F[FI["UOFF_HOST"]] = uoffs.ctypes.data
-        self.F[FI["MAX_ROWS"]] = int(self.meta_arr[self.ok, 4].max()) if len(self.ok) else 1          # no view has more rows than its root
         self.F[FI["CAP"] + CAP_BIG] = max(KM_BIG_BYTES - 1, 0)
         st = dict(caps=caps, d_ds=d_ds, n_words=n_words, reps=[], rec=[], done=0, tries=0)
         self._spec_levels(st, 0)
@@ -895,9 +895,11 @@ class ForestEngine(BatchEngine):
                          d_kinfo, work=0.0):
         be = self.be
         p = lambda b: (b if isinstance(b, int) else be.ptr(b)) if b is not None else None          # (a buffer, or an address inside one)
-        be.call("mprg_cluster_further", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(self.d_pool), be.ptr(d_prob), n_probs, k,
+        # (no view has more rows than the forest's largest root: the launch that only tall problems need is left out below that)
+        be.call("mprg_cluster_further_bounded", be.ptr(self.d_arena), be.ptr(d_sub), be.ptr(self.d_pool), be.ptr(d_prob), n_probs, k,
                 be.ptr(dd["d_of_row"]), p(d_labels), p(d_assign), be.ptr(d_wc), n_wc, be.ptr(d_wr), n_wr, be.ptr(d_scratch),
-                be.ptr(d_further), p(d_info), be.ptr(dd["gcodes"]), p(d_kinfo), be.stream, work=work)
+                be.ptr(d_further), p(d_info), be.ptr(dd["gcodes"]), p(d_kinfo), int(self.F[FI["MAX_ROWS"]]), be.stream, work=work,
+                label="mprg_cluster_further")
         self.counters["launches"] += 2
 
     # ------------------------------------------------------------------------------------------------ host views of the tables

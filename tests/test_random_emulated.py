@@ -50,7 +50,7 @@ def test_wide_views_take_the_fallback_paths(emu, N, L, S, C, p, monkeypatch):
 
 
 def test_gap_runs_reach_across_column_segments(emu, monkeypatch):
-    """k_gap_runs splits a wide view into 2 048-column segments: a run that begins before a segment (or covers whole segments) is
+    """k_gap_runs splits a wide view into 512-column segments: a run that begins before a segment (or covers whole segments) is
     counted backwards from the segment's start.  Rows with gap stretches across columns 2 048 and 4 096, variation inside them."""
     import numpy as np
     rng = np.random.default_rng(5)
@@ -112,8 +112,8 @@ def test_leaf_of_many_alleles_is_laid_out_by_its_wavefront(emu, monkeypatch):
     assert int(eng.tab["nseq"].max()) > 128
 
 
-def test_tall_view_takes_the_unbucketed_majority_path(emu, monkeypatch):
-    """More rows than the LDS member lists of k_cluster_majority hold (CF_ROWS)."""
+def test_tall_view_takes_the_wide_majority_workgroups(emu, monkeypatch):
+    """More rows than the LDS member lists of k_cluster_majority hold (CF_ROWS): k_cluster_majority_big's shared counters."""
     import numpy as np
     rng = np.random.default_rng(77)
     C = 48
@@ -238,3 +238,28 @@ def test_kmer_dictionary_by_many_workgroups(emu, monkeypatch):
     monkeypatch.setattr(pc, "ENGINE", "forest")
     pc.check_vs_oracle(emu, random_cases(61, 60), 5, 7)
     pc.check_vs_oracle(emu, random_cases(62, 30), 3, 3)
+
+
+def test_wide_and_tall_view_shares_a_rows_candidates_among_threads(emu, monkeypatch):
+    """More than 4 096 columns AND more rows than k_ungap_dedupe's LDS table: k_dedupe_scan_big's chunks are 8 rows and 32 threads
+    share a row's earlier rows (candidate classes); the view's rows are wide enough for k_cluster_hamming's group-per-row form and
+    k_ungap_hash's batched steps.  Four variants (one mutated column in every five, at different phases: the whole alignment is ONE
+    non-match interval), 530 rows drawn from them, a few with gaps (gapped twins of rows that are equal without gaps)."""
+    import numpy as np
+    rng = np.random.default_rng(31)
+    C, S = 4200, 530
+    base = rng.integers(0, 4, C)
+    variants = [base.copy()]
+    for v in range(3):
+        y = base.copy()
+        cols = np.arange(C)[np.arange(C) % 5 == v + 1]
+        y[cols] = (y[cols] + 1 + v) % 4
+        variants.append(y)
+    pick = rng.integers(0, len(variants), S)
+    pick[:8] = [3, 1, 3, 0, 2, 1, 0, 2]          # every variant's first row early, repeats in different candidate classes
+    txt = [np.frombuffer(b"ACGT", np.uint8)[variants[int(p)]].copy() for p in pick]
+    for i in range(5, S, 37):
+        txt[i][100 + i % 50:103 + i % 50] = ord("-")
+    text = "".join(f">w{i}\n{t.tobytes().decode()}\n" for i, t in enumerate(txt))
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    pc.check_vs_oracle(emu, [text], 2, 7)

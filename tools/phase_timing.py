@@ -14,12 +14,16 @@ from bench import make_batch
 from make_prg_amd.backend import HipBackend
 import make_prg_amd.forest as F
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "deep" else 2048
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] not in ("deep", "flat") else 2048
 lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "make_prg_amd", "_lib", "libmprg_hip_timing.so")
 if len(sys.argv) > 1 and sys.argv[1] == "deep":          # python tools/phase_timing.py deep S C: one hierarchical alignment (-N 7)
     from make_prg_amd.msa import MSA, Record
     from make_prg_amd.utils.synthetic import synth_rows_deep
     msas = [MSA([Record(r, f"s{i}", f"s{i}") for i, r in enumerate(synth_rows_deep(0, int(sys.argv[2]), int(sys.argv[3])))])]
+elif len(sys.argv) > 1 and sys.argv[1] == "flat":          # python tools/phase_timing.py flat S C: BASELINE config D's generator (-N 7)
+    from make_prg_amd.msa import MSA, Record
+    from make_prg_amd.utils.synthetic import synth_rows
+    msas = [MSA([Record(r, f"s{i}", f"s{i}") for i, r in enumerate(synth_rows(0, int(sys.argv[2]), int(sys.argv[3]), 8))])]
 else:
     msas = make_batch(list(range(n)), 16)[1]
 be = HipBackend(0, lib_path=lib)
