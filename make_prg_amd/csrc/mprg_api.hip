@@ -43,6 +43,7 @@ static const int g_dd_threads = env_threads("MPRG_DD_THREADS", BLOCK_VIEW, 512);
 static const int g_km_threads = env_threads("MPRG_KM_THREADS", 256);
 static const int g_km_wide_threads = env_threads("MPRG_KM_WIDE_THREADS", 1024);
 static const int g_kp_threads = env_threads("MPRG_KP_THREADS", 0);
+static const int g_kms_threads = env_threads("MPRG_KMS_THREADS", 128, 128);          // the small KMeans form: 64 or 128 threads per fit
 // small views by a wavefront each, several per workgroup (k_partition_wave, ...): MPRG_WAVE_VIEWS=0 keeps a workgroup per view
 // mprg_cluster_further: problems that fit a workgroup's LDS in one workgroup and launch (k_cluster_further_one); MPRG_CF_ONE=0: two launches for all
 static const int g_cf_one = [] { const char *e = getenv("MPRG_CF_ONE"); return (e && atoi(e) == 0) ? 0 : 1; }();
@@ -368,7 +369,7 @@ int mprg_kmeans_fit_small(const int64_t *prob, const int32_t *kinfo, const int32
                           int32_t *km_status, void *stream) {
   if (n_fits <= 0) return 0;
   if (n_init > KMS_RMAX) return fail("mprg_kmeans_fit_small: n_init must be <= 10");
-#define KMS_LAUNCH(KCH) hipLaunchKernelGGL((k_kmeans_restart_select_small<KCH>), dim3((unsigned)n_fits), dim3(128), 0, (hipStream_t)stream, prob, \
+#define KMS_LAUNCH(KCH) hipLaunchKernelGGL((k_kmeans_restart_select_small<KCH>), dim3((unsigned)n_fits), dim3(g_kms_threads), 0, (hipStream_t)stream, prob, \
                                            kinfo, fit_list, n_init, uniforms_dev, xcounts, ws, labels, km_info, km_status)
   if (small_class == 0) KMS_LAUNCH(36);
   else if (small_class == 1) KMS_LAUNCH(KM_KMAX * KM_KMAX);

@@ -21,7 +21,10 @@ def pmc(name):
 fetch, write = pmc("pmc_FETCH_SIZE.csv.gz"), pmc("pmc_WRITE_SIZE.csv.gz")
 # cells each kernel visits in the config-D build (root view + its one child view, S x C each; the child is the selected view)
 ALG = {"k_column_masks": 2 * cells, "k_gap_runs": 2 * cells, "k_partition": 2 * cells, "k_ungap_hash": cells, "k_ungap_hash_u": cells,
-       "k_ungap_dedupe": cells, "k_dedupe_scan_big": None, "k_cluster_majority": cells, "k_cluster_hamming": cells, "k_emit_alleles": None, "k_ingest": cells}
+       "k_ungap_dedupe": cells, "k_dedupe_scan_big": None, "k_cluster_majority": cells, "k_cluster_majority_big": cells, "k_cluster_hamming": cells, "k_emit_alleles": None, "k_ingest": cells}
+# bytes a kernel cannot avoid moving (reads + writes of its step), where that differs from the cells visited
+MUST = {"k_ingest": 3 * cells, "k_ungap_hash": 3 * cells, "k_column_masks": 2 * cells, "k_gap_runs": 2 * cells, "k_cluster_majority_big": cells,
+        "k_cluster_majority": cells, "k_cluster_hamming": cells, "k_ungap_hash_u": cells}
 rows = []
 for n, (calls, ns) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
     if not n.startswith("k_") or ns < 50_000:
@@ -30,9 +33,10 @@ for n, (calls, ns) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
     alg = ALG.get(n)
     rows.append(dict(kernel=n, launches=calls, ms=round(ns / 1e6, 3), hbm_MB=round(hbm / 1e6, 1), hbm_GBps=round(hbm / ns, 1) if ns else None,
                      hbm_frac_of_8TBps=round(hbm / ns / 8000, 4), algorithmic_MB=alg and round(alg / 1e6, 1),
-                     algorithmic_GBps=alg and round(alg / ns, 1), traffic_over_algorithmic=alg and round(hbm / alg, 2)))
+                     algorithmic_GBps=alg and round(alg / ns, 1), traffic_over_algorithmic=alg and round(hbm / alg, 2),
+                     must_move_MB=MUST.get(n) and round(MUST[n] / 1e6, 1), traffic_over_must_move=MUST.get(n) and round(hbm / MUST[n], 2)))
 json.dump(rows, open(os.path.join(d, "kernels.json"), "w"), indent=1)
-print("| kernel | launches | ms | HBM MB (2 x FETCH + WRITE) | HBM GB/s | frac of 8 TB/s | algorithmic MB | traffic / algorithmic |")
-print("|---|---|---|---|---|---|---|---|")
+print("| kernel | launches | ms | HBM MB (2 x FETCH + WRITE) | HBM GB/s | frac of 8 TB/s | algorithmic MB (cells visited) | traffic / algorithmic | must move MB (reads + writes) | traffic / must move |")
+print("|---|---|---|---|---|---|---|---|---|---|")
 for r in rows:
-    print(f"| `{r['kernel']}` | {r['launches']} | {r['ms']} | {r['hbm_MB']} | {r['hbm_GBps']} | {r['hbm_frac_of_8TBps']} | {r['algorithmic_MB'] or '—'} | {r['traffic_over_algorithmic'] or '—'} |")
+    print(f"| `{r['kernel']}` | {r['launches']} | {r['ms']} | {r['hbm_MB']} | {r['hbm_GBps']} | {r['hbm_frac_of_8TBps']} | {r['algorithmic_MB'] or '—'} | {r['traffic_over_algorithmic'] or '—'} | {r['must_move_MB'] or '—'} | {r['traffic_over_must_move'] or '—'} |")
