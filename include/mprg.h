@@ -228,7 +228,8 @@ int mprg_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const int32
  *   xbytes (optional): the raw counts as BYTES, rows of pitch round_up(V, 4) made an odd number of 4-byte words, problem p at byte
  *     8 * prob[p][X_OFF] of a buffer as large as xcounts; what the wide fits stream instead of the centred doubles (an eighth of the bytes);
  *   with_tables = 0: the sample-sample tables of the seeding are NOT made (2.5 D^2 chains per problem) — the wide fits compute the few
- *     dozen rows they ask for; only mprg_kmeans_fit_wide may fit such a problem.
+ *     dozen rows they ask for; only mprg_kmeans_fit_wide may fit such a problem.  1: made, by 32 x 32 tiles of sample pairs staged through
+ *     LDS; 2: made by a thread per table element (the form before round 5, kept for comparison: the same doubles).
  * list: rows of `prob` (NULL: 0..n-1). */
 int mprg_kmeans_prepare_big(const int64_t *prob, const double *xcounts, double *ws, const int32_t *list, int n_list, uint8_t *xbytes,
                             int with_tables, void *stream);

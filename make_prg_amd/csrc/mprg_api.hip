@@ -43,6 +43,8 @@ static const int g_dd_threads = env_threads("MPRG_DD_THREADS", BLOCK_VIEW, 512);
 static const int g_km_threads = env_threads("MPRG_KM_THREADS", 256);
 static const int g_km_wide_threads = env_threads("MPRG_KM_WIDE_THREADS", 1024);
 static const int g_kp_threads = env_threads("MPRG_KP_THREADS", 0);
+// the sample-sample tables of K6's global form by tiles of pairs through LDS (k_kmeans_prepare_tables_tiled); MPRG_KP_TILED=0: a thread per element
+static const int g_kp_tiled = [] { const char *e = getenv("MPRG_KP_TILED"); return (e && atoi(e) == 0) ? 0 : 1; }();
 static const int g_kms_threads = env_threads("MPRG_KMS_THREADS", 128, 128);          // the small KMeans form: 64 or 128 threads per fit
 // small views by a wavefront each, several per workgroup (k_partition_wave, ...): MPRG_WAVE_VIEWS=0 keeps a workgroup per view
 // mprg_cluster_further: problems that fit a workgroup's LDS in one workgroup and launch (k_cluster_further_one); MPRG_CF_ONE=0: two launches for all
@@ -242,7 +244,9 @@ int mprg_kmeans_prepare_big(const int64_t *prob, const double *xcounts, double *
   if (with_tables) {          // a few big problems: more workgroups per problem than the pan-genome launches' KP_PARTS
     int parts = 4096 / n_list;
     parts = parts < KP_PARTS ? KP_PARTS : (parts > 1024 ? 1024 : parts);
-    LAUNCH(k_kmeans_prepare_tables, (long long)n_list * parts, 256, stream, list, prob, xcounts, ws, xbytes, parts, DS_HOST);
+    // by 32 x 32 tiles of sample pairs staged through LDS (with_tables = 2 or MPRG_KP_TILED=0: a thread per table element, the form before)
+    if (with_tables != 2 && g_kp_tiled) LAUNCH(k_kmeans_prepare_tables_tiled, (long long)n_list * parts, KPT_THREADS, stream, list, prob, ws, parts, DS_HOST);
+    else LAUNCH(k_kmeans_prepare_tables, (long long)n_list * parts, 256, stream, list, prob, xcounts, ws, xbytes, parts, DS_HOST);
   }
   return check_launch("k_kmeans_prepare");
 }
@@ -255,7 +259,8 @@ static int d_kmeans_prepare(const int64_t *prob, int n_probs, const double *xcou
   if (n_lds > 0 && (lds_bytes <= 0 || lds_bytes > MPRG_KMEANS_PREPARE_LDS_MAX)) return fail("mprg_kmeans_prepare: lds_bytes out of range");
   if (n_other > 0) {
     LAUNCH(k_kmeans_prepare, n_other, 256, stream, other_list, prob, xcounts, ws, 0, (uint8_t *)nullptr, dc);
-    LAUNCH(k_kmeans_prepare_tables, (long long)n_other * KP_PARTS, 256, stream, other_list, prob, xcounts, ws, (uint8_t *)nullptr, KP_PARTS, dc);
+    if (g_kp_tiled) LAUNCH(k_kmeans_prepare_tables_tiled, (long long)n_other * KPT_PARTS, KPT_THREADS, stream, other_list, prob, ws, KPT_PARTS, dc);
+    else LAUNCH(k_kmeans_prepare_tables, (long long)n_other * KP_PARTS, 256, stream, other_list, prob, xcounts, ws, (uint8_t *)nullptr, KP_PARTS, dc);
   }
   if (n_lds > 0) {
     if (lds_bytes > 64 * 1024) {     // beyond the default per-workgroup limit: gfx950 has 160 KB of LDS per CU, one such workgroup fits

@@ -72,8 +72,11 @@ KM_SPLIT_BELOW = int(os.environ.get("MPRG_KM_SPLIT_BELOW", "0"))
 # dictionary, ten restarts side by side in one workgroup queue behind one CU (profiles/r04/deep_alignment.md); 0 = never
 KM_BIG_BYTES = int(os.environ.get("MPRG_KM_BIG_BYTES", str(1 << 20)))
 # ... and from this size on the level's big problems are prepared WITHOUT the sample-sample tables of the seeding (mprg_kmeans_prepare_big, with_tables = 0:
-# 2.5 D^2 chains per problem); the wide fits then compute the few dozen rows they ask for themselves
-KM_NO_TABLES_BYTES = int(os.environ.get("MPRG_KM_NO_TABLES_BYTES", str(160 << 20)))
+# 2.5 D^2 chains per problem, 32 D^2 bytes); the wide fits then compute the few dozen rows they ask for themselves.  Until the tables were made
+# by tiles (k_kmeans_prepare_tables_tiled, round 5) this was 160 MB (~1 500 sequences x 16 384 k-mers); with them the tables pay for
+# themselves at every size measured (10 000 x 20 000 hierarchical: 0.46 s for the tables, 0.58 s less in the fits), so only problems whose
+# tables would take tens of GB go without
+KM_NO_TABLES_BYTES = int(os.environ.get("MPRG_KM_NO_TABLES_BYTES", str(4 << 30)))
 # ... and a big level of at most this many problems fits EVERY round's general-form KMeans at once (_kloop_rounds, spec_k): a round is
 # ten wide workgroups per problem — with five problems fifty CUs of 256, nine rounds one after the other; 0 = never
 KM_SPEC_PROBLEMS = int(os.environ.get("MPRG_KM_SPEC_PROBLEMS", "64"))

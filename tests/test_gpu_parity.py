@@ -171,3 +171,11 @@ def test_kmer_dictionary_and_counts_by_many_workgroups(hip, golden_integration, 
     pc.check_vs_oracle(hip, random_cases(62, 30), 3, 3)
     assert pc.check_integration(hip, golden_integration) >= 30
     assert calls.count("mprg_kmer_dictionary_parts") >= 3 and calls.count("mprg_kmer_counts_parts") >= 3 and "mprg_kmer_dictionary" not in calls
+
+
+def test_sample_tables_by_tiles_equal_the_chains_by_threads(hip):
+    """K6's sample-sample tables of the global form (k_kmeans_prepare_tables_tiled: all chains of a sample pair advanced together over
+    LDS-staged features) are the doubles of the thread-per-element kernel: every block boundary of the CPU kernels' K loops, and problems
+    of the size a deep alignment's levels hold."""
+    from tests.kmeans_tables import SHAPES, check_tiled_tables
+    assert check_tiled_tables(hip, SHAPES + [(300, 3000), (700, 4100), (130, 6200)]) == []
