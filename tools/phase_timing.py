@@ -4,10 +4,14 @@ Build it first (in the container: hipcc cross-compiles; the .so travels with gpu
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-unused-function -DKM_PHASE_TIMING \
         -Iinclude make_prg_amd/csrc/mprg_api.hip -o make_prg_amd/_lib/libmprg_hip_timing.so
 The timers perturb kernels that run many short workgroups (one atomic per workgroup and mark): trust them for the KMeans
-fit, not for the small-view partition."""
+fit, not for the small-view partition.
+The tool runs the PER-ROUND loop (MPRG_KLOOP=rounds unless the caller sets it): the fused-loop kernels of the diagnostic build fault on the
+device (round 5: a memory access fault at a low address in k_cluster_loop_small; the product build of the same sources passes every GPU
+test, and the CPU emulation of the diagnostic build passes the forest cases) — not looked into further, the per-round kernels carry the marks."""
 import ctypes
 import os
 import sys
+os.environ.setdefault("MPRG_KLOOP", "rounds")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bench import make_batch
