@@ -45,6 +45,8 @@ static const int g_km_wide_threads = env_threads("MPRG_KM_WIDE_THREADS", 1024);
 static const int g_kp_threads = env_threads("MPRG_KP_THREADS", 0);
 // the sample-sample tables of K6's global form by tiles of pairs through LDS (k_kmeans_prepare_tables_tiled); MPRG_KP_TILED=0: a thread per element
 static const int g_kp_tiled = [] { const char *e = getenv("MPRG_KP_TILED"); return (e && atoi(e) == 0) ? 0 : 1; }();
+// the selection of wide fits: predict() in a launch of its own, KPW_PARTS workgroups per fit (MPRG_KPW_SPLIT=0: inside the selection's one workgroup)
+static const int g_kpw_split = [] { const char *e = getenv("MPRG_KPW_SPLIT"); return (e && atoi(e) == 0) ? 0 : 1; }();
 static const int g_kms_threads = env_threads("MPRG_KMS_THREADS", 128, 128);          // the small KMeans form: 64 or 128 threads per fit
 // small views by a wavefront each, several per workgroup (k_partition_wave, ...): MPRG_WAVE_VIEWS=0 keeps a workgroup per view
 // mprg_cluster_further: problems that fit a workgroup's LDS in one workgroup and launch (k_cluster_further_one); MPRG_CF_ONE=0: two launches for all
@@ -321,6 +323,12 @@ static int d_kmeans_fit_split(const int64_t *prob, const int32_t *kinfo, const i
                        n_init, uniforms_dev, xcounts, ws, km_status);
   if (check_launch("k_kmeans_restart_one") != 0) return -2;
   // (the selection predicts the labels — D x k chains as long as the k-mer dictionary: a big fit's takes the wide workgroup and the bytes too)
+  if (threads > 64 && g_kpw_split) {          // wide fits: predict() by KPW_PARTS workgroups per fit
+    LAUNCH(k_kmeans_select_only_list, n_fits, threads, stream, prob, kinfo, fit_list, n_init, xcounts, ws, labels, km_info, xbytes);
+    LAUNCH(k_kmeans_predict_list, (long long)n_fits * KPW_PARTS, threads, stream, prob, kinfo, fit_list, xcounts, ws, labels, km_info, xbytes, KPW_PARTS);
+    LAUNCH(k_kmeans_predict_finish, (n_fits + 63) / 64, 64, stream, kinfo, fit_list, n_fits, km_info);
+    return check_launch("k_kmeans_predict_list");
+  }
   LAUNCH(k_kmeans_select_list, n_fits, threads > 64 ? threads : 256, stream, prob, kinfo, fit_list, n_init, xcounts, ws, labels, km_info, xbytes);
   return check_launch("k_kmeans_select_list");
 }

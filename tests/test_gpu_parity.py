@@ -177,5 +177,6 @@ def test_sample_tables_by_tiles_equal_the_chains_by_threads(hip):
     """K6's sample-sample tables of the global form (k_kmeans_prepare_tables_tiled: all chains of a sample pair advanced together over
     LDS-staged features) are the doubles of the thread-per-element kernel: every block boundary of the CPU kernels' K loops, and problems
     of the size a deep alignment's levels hold."""
-    from tests.kmeans_tables import SHAPES, check_tiled_tables
+    from tests.kmeans_tables import SHAPES, check_lds_tables, check_tiled_tables
     assert check_tiled_tables(hip, SHAPES + [(300, 3000), (700, 4100), (130, 6200)]) == []
+    assert check_lds_tables(hip) == []          # K6's LDS form: a thread per pair over the matrix in LDS

@@ -269,5 +269,6 @@ def test_sample_tables_by_tiles_equal_the_chains_by_threads(emu):
     """k_kmeans_prepare_tables_tiled advances all chains of a sample pair together over LDS-staged features; the tables must be the
     doubles of k_kmeans_prepare_tables (a thread per element walking km_gemm_dot_v / km_chain4 / km_gemv_col / km_euclid): shapes on
     both sides of every block boundary (256 / 512 of the dgemm K loop, 2 048 of dgemv_t, V mod 4 and mod 8, D mod 4 and the 32 x 32 tiles)."""
-    from tests.kmeans_tables import check_tiled_tables
+    from tests.kmeans_tables import check_lds_tables, check_tiled_tables
     assert check_tiled_tables(emu) == []
+    assert check_lds_tables(emu) == []          # K6's LDS form: a thread per pair over the matrix in LDS
