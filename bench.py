@@ -663,7 +663,7 @@ def main():
             top_e = max(ps[0].get("entry_points", [{}]), key=lambda e_: e_.get("ms", 0.0)) if ps[0].get("entry_points") else None
             deep_roof = None
             if top_e and top_e.get("achieved_GBps"):
-                deep_roof = dict(bound="hbm", entry_point=top_e["entry_point"], kernel=KERNEL_OF.get(top_e["entry_point"], "k_kmeans_restart_wide + k_kmeans_select_list"),
+                deep_roof = dict(bound="hbm", entry_point=top_e["entry_point"], kernel=KERNEL_OF.get(top_e["entry_point"], "k_kmeans_restart_wide + k_kmeans_select_only_list + k_kmeans_predict_list"),
                                  ms=top_e["ms"], launches=top_e["calls"], algorithmic_bytes=top_e["algorithmic_bytes"], achieved=top_e["achieved_GBps"],
                                  peak=HBM_PEAK_GBS, unit="GB/s", frac=round(top_e["achieved_GBps"] / HBM_PEAK_GBS, 6),
                                  traffic=None, traffic_note="FETCH_SIZE / WRITE_SIZE passes of the same command: profiles/r05/deep/")

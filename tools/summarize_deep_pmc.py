@@ -39,9 +39,10 @@ for k, (calls, ns) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
 wide = ep.get("mprg_kmeans_fit_wide")
 roof = None
 if wide and wide.get("algorithmic_bytes"):
-    ns = stats["k_kmeans_restart_wide"][1] + stats["k_kmeans_select_list"][1]
-    hbm = sum(r["hbm_bytes"] for r in rows if r["kernel"] in ("k_kmeans_restart_wide", "k_kmeans_select_list"))
-    roof = dict(entry_point="mprg_kmeans_fit_wide", kernels="k_kmeans_restart_wide + k_kmeans_select_list", bound="hbm",
+    WIDE = ("k_kmeans_restart_wide", "k_kmeans_select_list", "k_kmeans_select_only_list", "k_kmeans_predict_list", "k_kmeans_predict_finish")
+    ns = sum(stats[k][1] for k in WIDE if k in stats)
+    hbm = sum(r["hbm_bytes"] for r in rows if r["kernel"] in WIDE)
+    roof = dict(entry_point="mprg_kmeans_fit_wide", kernels="k_kmeans_restart_wide + k_kmeans_select_only_list + k_kmeans_predict_list (+ _finish)", bound="hbm",
                 algorithmic_bytes=wide["algorithmic_bytes"], ms_events=wide["ms"], ms_rocprofv3=round(ns / 1e6, 3),
                 achieved=round(wide["algorithmic_bytes"] / max(ns, 1), 3), peak=8000.0, unit="GB/s",
                 frac=round(wide["algorithmic_bytes"] / max(ns, 1) / 8000.0, 6), traffic=hbm,
