@@ -349,31 +349,42 @@ class ForestEngine(BatchEngine):
         r = float((self.meta_arr[ok, 4] * self.meta_arr[ok, 5]).sum()) / max(float(donor["cells"]), 1.0)
         if not (1.0 / DONOR_MAX_RATIO <= r <= DONOR_MAX_RATIO):          # (a batch of another order of magnitude says little)
             return None
-        src = donor["levels"]
-        unit = {}
-        for (st, c), (cs, cc) in _CAP_COLS.items():
-            unit[(st, c)] = max([1.0] + [float(lv[st][c]) / max(float(lv[cs][cc]), 1.0) for lv in src])
-
-        def cap_of(lv, st, c):
-            cs, cc = _CAP_COLS[(st, c)]
-            pred, n_pred = (r * float(lv[st][c]), r * float(lv[cs][cc])) if lv is not None else (0.0, 0.0)
-            # the items that effectively make up the total: the counted ones — or fewer: a count of RARE items (the problems of one
-            # LDS class among thousands: 12 predicted, 30 seen) scatters like its own value, a total of a few big items like their number
-            n_eff = min(n_pred, pred / max(unit[(st, c)], 1.0))
-            return int(np.ceil(pred * (PLAN_HEAD + PLAN_SPREAD / np.sqrt(n_eff + 1.0)) + PLAN_FLOOR * unit[(st, c)]))
+        # (everything that depends on the donor alone is kept with it: a pipeline sizes every chunk from the same donor, and a 3 750-alignment
+        #  pass is 50 ms — the 1.5 ms of Python loops this used to take were half of what a first pass lost against a planned one)
+        pc = donor.get("_pred")
+        if pc is None:
+            src = donor["levels"]
+            cols = list(_CAP_COLS)
+            A = np.asarray([[float(lv[st][c]) for (st, c) in cols] for lv in src], np.float64).reshape(len(src), len(cols))
+            B = np.asarray([[float(lv[_CAP_COLS[k][0]][_CAP_COLS[k][1]]) for k in cols] for lv in src], np.float64).reshape(len(src), len(cols))
+            unit = np.maximum(1.0, (A / np.maximum(B, 1.0)).max(axis=0)) if len(src) else np.ones(len(cols))
+            items = np.asarray([[float(lv[0][5 + q]) for q in range(5)] for lv in src], np.float64).reshape(len(src), 5)
+            by_step = {s_: ([i for i, (st, _) in enumerate(cols) if st == s_], [c for (st, c) in cols if st == s_]) for s_ in range(6)}
+            pc = donor["_pred"] = dict(A=A, B=B, unit=unit, items=items, by_step=by_step)
+        A, B, unit, by_step = pc["A"], pc["B"], pc["unit"], pc["by_step"]
+        n_src = A.shape[0]
+        pred, n_pred = r * A, r * B
+        # the items that effectively make up a total: the counted ones — or fewer: a count of RARE items (the problems of one LDS class
+        # among thousands: 12 predicted, 30 seen) scatters like its own value, a total of a few big items like their number
+        n_eff = np.minimum(n_pred, pred / unit)
+        caps_all = np.ceil(pred * (PLAN_HEAD + PLAN_SPREAD / np.sqrt(n_eff + 1.0)) + PLAN_FLOOR * unit).astype(np.int64)
+        caps_none = np.ceil(PLAN_FLOOR * unit).astype(np.int64)          # (a level beyond the donor's: the floor's room only)
+        rpc_all = r * pc["items"]
 
         levels, n_front = [], len(ok)
         n_nodes, pool = len(ok), 0
         # (PLAN_SLACK_LEVELS levels more than the donor had, with the floor's room only: 0 — a batch that nests deeper than its donor
         #  stops at the level that must find an empty frontier and is enqueued again from there; every level costs ~60 launches)
-        for lv in list(src) + [None] * PLAN_SLACK_LEVELS:
+        for li in range(n_src + PLAN_SLACK_LEVELS):
+            row = caps_all[li] if li < n_src else caps_none
             out = {s_: np.zeros(HDR, np.int64) for s_ in range(6)}
-            for (st, c) in _CAP_COLS:
-                out[st][c] = cap_of(lv, st, c)
+            for s_, (idx, cs_) in by_step.items():
+                if idx:
+                    out[s_][cs_] = row[idx]
             out[0][14] = n_front
             for c in (0, 3, 4):          # views, fused views, other views: at most the frontier
                 out[0][c] = min(int(out[0][c]), n_front)
-            items = [r * float(lv[0][5 + q]) for q in range(5)] if lv is not None else [0.0] * 5
+            items = rpc_all[li] if li < n_src else np.zeros(5)
             out["rpc_idx"] = next((i for i in range(4) if items[i] >= 1024), 4)
             for c in range(PREPARE_CLASSES):
                 out[4][16 + c] = PREPARE_LDS_BOUNDS[c]
