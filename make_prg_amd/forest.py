@@ -104,6 +104,7 @@ _CAP_COLS = {(0, 0): (0, 14), (0, 1): (0, 0), (0, 3): (0, 14), (0, 4): (0, 14), 
              (3, 0): (2, 0), (3, 1): (3, 0), (3, 2): (3, 0), (3, 3): (3, 0),
              (4, 0): (3, 0), (4, 1): (3, 0), (4, 2): (3, 0), (4, 3): (3, 0), (4, 4): (3, 0), (4, 5): (3, 0), (4, 6): (3, 0),
              (5, 0): (3, 0), (5, 1): (5, 0), (5, 2): (5, 0)}
+_CAP_BY_STEP = {s_: ([i for i, (st, _) in enumerate(_CAP_COLS) if st == s_], [c for (st, c) in _CAP_COLS if st == s_]) for s_ in range(6)}
 PLAN_HEAD = float(os.environ.get("MPRG_PLAN_HEAD", "1.35"))          # headroom of a predicted total ...
 PLAN_SPREAD = float(os.environ.get("MPRG_PLAN_SPREAD", "24"))        # ... + this / sqrt(items behind it)
 PLAN_SLACK_LEVELS = int(os.environ.get("MPRG_PLAN_SLACK_LEVELS", "0"))
@@ -355,11 +356,13 @@ class ForestEngine(BatchEngine):
         if pc is None:
             src = donor["levels"]
             cols = list(_CAP_COLS)
-            A = np.asarray([[float(lv[st][c]) for (st, c) in cols] for lv in src], np.float64).reshape(len(src), len(cols))
-            B = np.asarray([[float(lv[_CAP_COLS[k][0]][_CAP_COLS[k][1]]) for k in cols] for lv in src], np.float64).reshape(len(src), len(cols))
+            # (a pipeline's donor is the chunk before: used once — so this, too, is array work: the levels' step blocks stacked per step)
+            M = [np.stack([np.asarray(lv[s_], np.float64) for lv in src]) if len(src) else np.zeros((0, HDR)) for s_ in range(6)]
+            A = np.stack([M[st][:, c] for (st, c) in cols], axis=1) if len(src) else np.zeros((0, len(cols)))
+            B = np.stack([M[_CAP_COLS[k][0]][:, _CAP_COLS[k][1]] for k in cols], axis=1) if len(src) else np.zeros((0, len(cols)))
             unit = np.maximum(1.0, (A / np.maximum(B, 1.0)).max(axis=0)) if len(src) else np.ones(len(cols))
-            items = np.asarray([[float(lv[0][5 + q]) for q in range(5)] for lv in src], np.float64).reshape(len(src), 5)
-            by_step = {s_: ([i for i, (st, _) in enumerate(cols) if st == s_], [c for (st, c) in cols if st == s_]) for s_ in range(6)}
+            items = M[0][:, 5:10].copy()
+            by_step = _CAP_BY_STEP
             pc = donor["_pred"] = dict(A=A, B=B, unit=unit, items=items, by_step=by_step)
         A, B, unit, by_step = pc["A"], pc["B"], pc["unit"], pc["by_step"]
         n_src = A.shape[0]
