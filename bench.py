@@ -49,7 +49,7 @@ KERNEL_OF = {"mprg_kmeans_restarts": "k_kmeans_restart", "mprg_kmeans_fit": "k_k
              "mprg_ungap_dedupe": "k_ungap_dedupe (+ k_dedupe_wave, k_ungap_hash, k_ungap_hash_u, k_dedupe_scan_big)", "mprg_emit_alleles": "k_emit_alleles",
              "mprg_cluster_loop[general]": "k_cluster_loop", "mprg_cluster_loop[small]": "k_cluster_loop_small",
              "mprg_cluster_further": "k_cluster_further_one (+ k_cluster_majority, k_cluster_majority_big, k_cluster_hamming)",
-             "mprg_kmeans_prepare": "k_kmeans_prepare_lds (+ k_kmeans_prepare, k_kmeans_prepare_tables)"}
+             "mprg_kmeans_prepare": "k_kmeans_prepare_lds (+ k_kmeans_prepare, k_kmeans_prepare_tables_tiled, k_kmeans_prepare_tables)"}
 
 
 def _text(seed):
