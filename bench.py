@@ -44,7 +44,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 DIGESTS = os.path.join(ROOT, "tests", "golden", "config_c_digests.bin")
 KERNEL_OF = {"mprg_kmeans_restarts": "k_kmeans_restart", "mprg_kmeans_fit": "k_kmeans_restart_select (persistent form: k_kmeans_fit)",
-             "mprg_kmeans_fit_small": "k_kmeans_restart_select_small", "mprg_kmeans_fit_split": "k_kmeans_restart_one + k_kmeans_select_list", "mprg_kmeans_fit_wave": "k_kmeans_fit_wave",
+             "mprg_kmeans_fit_small": "k_kmeans_restart_select_small", "mprg_kmeans_fit_split": "k_kmeans_restart_one + k_kmeans_select_list", "mprg_kmeans_fit_wave": "k_kmeans_fit_wave", "mprg_kmeans_fit_lds": "k_kmeans_fit_lds",
              "mprg_column_masks": "k_column_masks", "mprg_partition": "k_partition (+ k_partition_wave, k_partition_fused, k_gap_runs, k_pack_scan, k_pack_copy)",
              "mprg_ungap_dedupe": "k_ungap_dedupe (+ k_dedupe_wave, k_ungap_hash, k_ungap_hash_u, k_dedupe_scan_big)", "mprg_emit_alleles": "k_emit_alleles",
              "mprg_cluster_loop[general]": "k_cluster_loop", "mprg_cluster_loop[small]": "k_cluster_loop_small",

@@ -49,6 +49,8 @@ SIGNATURES = {
     "mprg_kmeans_fit_wave": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7),
     "mprg_kmeans_small_class": (c_int, [c_int64, c_int64, c_int, c_int]),
     "mprg_kmeans_fit_small": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7),
+    "mprg_kmeans_lds_class": (c_int, [c_int64, c_int64, c_int, c_int]),
+    "mprg_kmeans_fit_lds": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 7),
     "mprg_kmeans_select": (c_int, [c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 5),
     "mprg_cluster_further": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int] + [c_void_p] * 6),
     "mprg_cluster_further_bounded": (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_int] + [c_void_p] * 5

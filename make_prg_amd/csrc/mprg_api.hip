@@ -12,6 +12,7 @@
 #include "k_rows.inc"
 #include "k_kmer.inc"
 #include "k_kmeans.inc"
+#include "k_kmeans_lds.inc"
 #include "k_cluster.inc"
 #include "k_kloop.inc"
 #include "k_emit.inc"
@@ -48,6 +49,9 @@ static const int g_kp_tiled = [] { const char *e = getenv("MPRG_KP_TILED"); retu
 // the selection of wide fits: predict() in a launch of its own, KPW_PARTS workgroups per fit (MPRG_KPW_SPLIT=0: inside the selection's one workgroup)
 static const int g_kpw_split = [] { const char *e = getenv("MPRG_KPW_SPLIT"); return (e && atoi(e) == 0) ? 0 : 1; }();
 static const int g_kms_threads = env_threads("MPRG_KMS_THREADS", 128, 128);          // the small KMeans form: 64 or 128 threads per fit
+// the LDS form (k_kmeans_fit_lds): threads per fit by LDS class — the classes with fewer workgroups per CU get more threads
+static const int g_kml_threads[4] = {env_threads("MPRG_KML_THREADS0", 128, 256), env_threads("MPRG_KML_THREADS1", 128, 256),
+                                     env_threads("MPRG_KML_THREADS2", 256, 256), env_threads("MPRG_KML_THREADS3", 256, 256)};
 // small views by a wavefront each, several per workgroup (k_partition_wave, ...): MPRG_WAVE_VIEWS=0 keeps a workgroup per view
 // mprg_cluster_further: problems that fit a workgroup's LDS in one workgroup and launch (k_cluster_further_one); MPRG_CF_ONE=0: two launches for all
 static const int g_cf_one = [] { const char *e = getenv("MPRG_CF_ONE"); return (e && atoi(e) == 0) ? 0 : 1; }();
@@ -391,6 +395,20 @@ int mprg_kmeans_fit_small(const int64_t *prob, const int32_t *kinfo, const int32
   return check_launch("k_kmeans_restart_select_small");
 }
 
+int mprg_kmeans_lds_class(int64_t D, int64_t V, int k, int n_init) { return kml_class(D, V, k, n_init); }
+
+int mprg_kmeans_fit_lds(const int64_t *prob, const int32_t *kinfo, const int32_t *fit_list, int n_fits, int lds_class, int n_init,
+                        const double *uniforms_dev, const double *xcounts, double *ws, int32_t *labels, double *km_info,
+                        int32_t *km_status, void *stream) {
+  if (n_fits <= 0) return 0;
+  if (n_init < 1 || n_init > KML_RMAX) return fail("mprg_kmeans_fit_lds: n_init must be 1..10");
+  if (lds_class < 0 || lds_class >= KML_CLASSES) return fail("mprg_kmeans_fit_lds: lds_class must be 0..3 (mprg_kmeans_lds_class)");
+  const int bytes = kml_class_bytes(lds_class);
+  LAUNCH_LDS(k_kmeans_fit_lds, n_fits, g_kml_threads[lds_class], bytes, stream, prob, kinfo, fit_list, n_init, uniforms_dev, xcounts, ws, labels,
+             km_info, km_status, bytes);
+  return check_launch("k_kmeans_fit_lds");
+}
+
 int mprg_kmeans_select(const int64_t *prob, const int32_t *kinfo, int n_fits, int n_init, const double *xcounts,
                        double *ws, int32_t *labels, double *km_info, void *stream) {
   if (n_fits <= 0) return 0;
@@ -461,10 +479,16 @@ static int d_cluster_loop(const int64_t *views, const int64_t *prob, int n_probs
   if (n_probs <= 0) return 0;
   if (n_init < 1 || n_init > KM_RMAX) return fail("n_init must be 1..16");
   if (!gcodes || !uniform_offsets_host || !stats) return fail("mprg_cluster_loop: gcodes, uniform_offsets_host and stats are required");
-  if (!(forms & 7)) return fail("mprg_cluster_loop: forms must name a workgroup form (MPRG_LOOP_*)");
+  if (!(forms & (7 | MPRG_LOOP_LDS))) return fail("mprg_cluster_loop: forms must name a workgroup form (MPRG_LOOP_*)");
   KlUoff uoff;
   for (int k = 0; k <= KM_KMAX; ++k) uoff.v[k] = k >= 2 ? uniform_offsets_host[k] : 0;
   const bool small_ok = n_init <= KMS_RMAX;
+  // the LDS form first, a launch per class in ascending order (a problem whose next round needs more LDS stays active for the next
+  // launch; what no class holds is left to the general form below)
+  if ((forms & MPRG_LOOP_LDS) && n_init <= KML_RMAX)
+    for (int c = 0; c < KML_CLASSES; ++c)
+      LAUNCH_LDS(k_cluster_loop_lds, n_probs, g_kml_threads[c], kml_class_bytes(c), stream, prob, n_init, uniforms_dev, uoff, xcounts, ws, views, d_of_row,
+                 gcodes, scratch, labels, assign, km_info, km_status, num_clusters, active, stats, c, kml_class_bytes(c), dc);
   if (forms & MPRG_LOOP_GENERAL)
     LAUNCH(k_cluster_loop, n_probs, g_km_threads, stream, prob, n_init, uniforms_dev, uoff, xcounts, ws, views, d_of_row, gcodes, scratch, labels,
            assign, km_info, km_status, num_clusters, active, stats, (forms & MPRG_LOOP_SKIP_SMALL) && small_ok ? 1 : 0, dc);

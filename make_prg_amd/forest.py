@@ -56,10 +56,13 @@ DS_OVERFLOW, DS_F0, DS_N, DS_NNODES, DS_POOL_USED, DS_LEVEL, DS_NFAILED, DS_GLOB
 # per-step host
 SPECULATIVE = os.environ.get("MPRG_SPECULATIVE", "1") != "0"
 # launch lists of a KMeans round (hdr 86..92): wave form by LDS class, general workgroup form, small workgroup form
-KM_LISTS = (("mprg_kmeans_fit_wave", 0), ("mprg_kmeans_fit_wave", 1), ("mprg_kmeans_fit_wave", 2), ("mprg_kmeans_fit_wave", 3),
+# which forms small fits take: bit 0 wave form (measured slower on MI355X: profiles/r03/kmeans_forms.md), bit 1 small workgroups,
+# bit 2 (round 6, default) the LDS form for every fit it has a class for — the restarts' state in LDS (csrc/k_kmeans_lds.inc);
+# its classes use the wave form's list slots
+KM_MODE = int(os.environ.get("MPRG_KM_MODE", "6"))
+KM_LDS_ENTRY = "mprg_kmeans_fit_lds" if (KM_MODE & 4) else "mprg_kmeans_fit_wave"
+KM_LISTS = ((KM_LDS_ENTRY, 0), (KM_LDS_ENTRY, 1), (KM_LDS_ENTRY, 2), (KM_LDS_ENTRY, 3),
             ("mprg_kmeans_fit", None), ("mprg_kmeans_fit_small", 0), ("mprg_kmeans_fit_small", 1))
-# which forms small fits take: bit 0 wave form (measured slower on MI355X: profiles/r03/kmeans_forms.md), bit 1 small workgroups
-KM_MODE = int(os.environ.get("MPRG_KM_MODE", "2"))
 # a round's launch lists side by side on side streams: measured flat on MI355X (352 vs 354 ms per forest of 30 000 alignments,
 # profiles/r03/kmeans_forms.md), off by default
 KM_SIDE_STREAMS = os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0"
@@ -431,7 +434,7 @@ class ForestEngine(BatchEngine):
             uoffs[k_] = o_
         self._uoffs_host = uoffs
         small = bool(KM_MODE & 2)
-        self._set(DS=d_ds, UNIFORMS=self._d_uni, LOOP_FORMS=(1 | 8 | 2 | 4) if small else 1)
+        self._set(DS=d_ds, UNIFORMS=self._d_uni, LOOP_FORMS=(16 | 1) if (KM_MODE & 4) else ((1 | 8 | 2 | 4) if small else 1))
         self.F[FI["SIDE_STREAM"]] = be.side_ptr(0) if (small and KM_SIDE_STREAMS and be.n_side_streams >= 1 and be.side_ptr(0) != be.stream) else 0
         self.F[FI["UOFF_HOST"]] = uoffs.ctypes.data
         self.F[FI["CAP"] + CAP_BIG] = max(KM_BIG_BYTES - 1, 0)
@@ -770,19 +773,24 @@ class ForestEngine(BatchEngine):
             loop_args = (be.ptr(d_sub), be.ptr(d_ptab), P, N_INIT, be.ptr(self._d_uni), uoffs.ctypes.data, be.ptr(d_x), be.ptr(d_ws),
                          be.ptr(dd["d_of_row"]), be.ptr(dd["gcodes"]), be.ptr(d_scratch), be.ptr(d_labels), be.ptr(d_assign), be.ptr(d_info),
                          be.ptr(d_st), be.ptr(d_numcl), be.ptr(d_active), be.ptr(self.d_hdr))
-            side = small and KM_SIDE_STREAMS and be.profile is None and be.n_side_streams >= 1
+            lds = bool(KM_MODE & 4)
+            side = small and not lds and KM_SIDE_STREAMS and be.profile is None and be.n_side_streams >= 1
             if side:
                 be.fork(1)
-            be.call("mprg_cluster_loop", *loop_args, 1 | (8 if small else 0), be.stream, label=LOOP_GENERAL)
+            if lds:          # the LDS form first, a launch per class; then the general form for the rounds no class holds
+                be.call("mprg_cluster_loop", *loop_args, 16, be.stream, label=LOOP_SMALL)
+                ev = self._last_event(LOOP_SMALL)
+                km_events.append(ev and ev + (LOOP_SMALL,))
+            be.call("mprg_cluster_loop", *loop_args, 1 | (8 if (small and not lds) else 0), be.stream, label=LOOP_GENERAL)
             ev = self._last_event(LOOP_GENERAL)
             km_events.append(ev and ev + (LOOP_GENERAL,))
-            if small:
+            if small and not lds:
                 be.call("mprg_cluster_loop", *loop_args, 2 | 4, be.side_ptr(0) if side else be.stream, side=0 if side else None, label=LOOP_SMALL)
                 ev = self._last_event(LOOP_SMALL)
                 km_events.append(ev and ev + (LOOP_SMALL,))
             if side:
                 be.join(1)
-            self.counters["launches"] += 2 if small else 1
+            self.counters["launches"] += 5 if lds else (2 if small else 1)
         else:
             self._kloop_rounds(P, d_sub, d_ptab, d_kinfo, d_x, d_ws, d_labels, d_assign, d_info, d_st, d_wc, n_wc, d_wr, n_wr, d_scratch,
                                d_further, dd, km_events, cf_events, wide=big, d_xb=d_xb, spec_k=spec_k and big, lo=lo)
@@ -792,12 +800,12 @@ class ForestEngine(BatchEngine):
         self._plan_note(rec, 5, h[:3])
         n_splits, rows_sp, n_child = (int(x) for x in h[:3])
         fits, cf_cells = int(h[80]), float(h[84:85].view(np.float64)[0])
-        kb = {"mprg_kmeans_fit_wave": float(h[81:82].view(np.float64)[0]), "mprg_kmeans_fit": float(h[85:86].view(np.float64)[0]),
+        kb = {KM_LDS_ENTRY: float(h[81:82].view(np.float64)[0]), "mprg_kmeans_fit": float(h[85:86].view(np.float64)[0]),
               "mprg_kmeans_fit_small": float(h[93:94].view(np.float64)[0])}
         km_bytes = sum(kb.values())
         if fused:          # a fused launch's algorithmic bytes: its fits' 8 D V (iterations + n_init) + the cells its cluster_further visits
             kb = {LOOP_GENERAL: kb["mprg_kmeans_fit"], LOOP_SMALL: kb["mprg_kmeans_fit_small"]}
-            kb[LOOP_SMALL if (KM_MODE & 2) else LOOP_GENERAL] += cf_cells
+            kb[LOOP_SMALL if (KM_MODE & 6) else LOOP_GENERAL] += cf_cells
         if h[82]:
             raise MprgError("KMeans empty-cluster relocation: the selection ran out of frames (more than 5^10 samples in a fit)")
         self.counters["fits"] += fits

@@ -328,9 +328,72 @@ def hip_runtimes_mapped() -> List[str]:
     return sorted(seen)
 
 
+SHM_FRACTION = float(os.environ.get("MPRG_SEGMENT_SHM_FRACTION", "0.3"))          # of what /dev/shm and MemAvailable leave, all local ranks together
+_SEGMENT_DIRS: List[str] = []                         # private in-memory directories of this process (removed at exit and on SIGTERM / SIGINT)
+
+
+def _remove_segment_dirs():
+    import shutil
+    while _SEGMENT_DIRS:
+        shutil.rmtree(_SEGMENT_DIRS.pop(), ignore_errors=True)
+
+
+def _sweep_stale_segment_dirs(root: str = "/dev/shm"):
+    """Directories of earlier runs of this user whose process is gone (a rank that was killed outright): their files are memory."""
+    import shutil
+    tag = f"mprg_{os.getuid()}_"
+    try:
+        names = [n for n in os.listdir(root) if n.startswith(tag)]
+    except OSError:
+        return
+    for name in names:
+        parts = name.split("_")
+        try:
+            pid = int(parts[2])
+            os.kill(pid, 0)                           # (raises when no such process)
+        except (IndexError, ValueError):
+            continue
+        except ProcessLookupError:
+            path = os.path.join(root, name)
+            if os.path.isdir(path) and not os.path.islink(path) and os.stat(path).st_uid == os.getuid():
+                shutil.rmtree(path, ignore_errors=True)
+        except PermissionError:
+            pass
+
+
+def _private_shm_dir() -> str:
+    """A directory of this process alone in /dev/shm (mode 0700, name unpredictable: mkdtemp), removed when the process ends —
+    normally, by an exception, or by the SIGTERM torchrun sends the peers of a rank that failed."""
+    import atexit
+    import signal
+    import tempfile
+    _sweep_stale_segment_dirs()
+    path = tempfile.mkdtemp(prefix=f"mprg_{os.getuid()}_{os.getpid()}_", dir="/dev/shm")
+    if not _SEGMENT_DIRS:
+        atexit.register(_remove_segment_dirs)
+        for sig in (signal.SIGTERM, signal.SIGINT):
+            prev = signal.getsignal(sig)
+
+            def handler(signum, frame, prev=prev):
+                _remove_segment_dirs()
+                if callable(prev):
+                    prev(signum, frame)
+                else:
+                    signal.signal(signum, signal.SIG_DFL)
+                    os.kill(os.getpid(), signum)
+            try:
+                signal.signal(sig, handler)
+            except ValueError:                        # (not the main thread: atexit still runs)
+                pass
+    _SEGMENT_DIRS.append(path)
+    return path
+
+
 def segment_prefix(options, rank: int, files: List[Path]) -> str:
-    """Where this rank writes its segment files: in memory (/dev/shm) when the shard's outputs fit comfortably (they are ~4x the
-    inputs with -O a), else next to the run's output.  MPRG_SEGMENT_DIR overrides."""
+    """Where this rank writes its segment files: in memory when the shard's outputs fit comfortably (they are ~4x the inputs with
+    -O a) — a PRIVATE directory under /dev/shm (_private_shm_dir), at most SHM_FRACTION of what is free there and in memory for all
+    local ranks together —, else next to the run's output.  MPRG_SEGMENT_DIR overrides (MPRG_SEGMENT_DIR=/dev/shm forces the
+    in-memory directory, any other value is used as it is)."""
     base = f"{os.path.basename(options.output_prefix)}.rank{rank}"
     seg_dir = os.environ.get("MPRG_SEGMENT_DIR")
     if seg_dir is None:
@@ -340,12 +403,12 @@ def segment_prefix(options, rank: int, files: List[Path]) -> str:
             st = os.statvfs("/dev/shm")
             avail_kib = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1])
             world_local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
-            if need * world_local < 0.5 * min(st.f_bavail * st.f_frsize, avail_kib * 1024):
+            if need * world_local < SHM_FRACTION * min(st.f_bavail * st.f_frsize, avail_kib * 1024):
                 seg_dir = "/dev/shm"
         except Exception:
             pass
     if seg_dir == "/dev/shm":
-        base = f"mprg_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{base}"
+        seg_dir = _private_shm_dir()
     return os.path.join(seg_dir, base)
 
 
@@ -382,6 +445,7 @@ def run_ranks(mine: List[Path], options, backend, dist, rank: int, world: int) -
                 os.remove(opts.output_prefix + suffix)
             except OSError:
                 pass
+        _remove_segment_dirs()
     return n
 
 

@@ -10,7 +10,8 @@ def run_kmeans_fits(be, fits, n_init=10, path="global", n_slots=3):
     "one-launch" = mprg_kmeans_fit without scratch slots (a workgroup per fit: restarts, then selection);
     "fit" = mprg_kmeans_fit (persistent workgroups, per-restart arrays in `n_slots` scratch slots, selection fused);
     "wave" = mprg_kmeans_fit_wave by LDS class through fit lists (one wavefront per fit, restart state in LDS); the fits without
-    a class take mprg_kmeans_fit with a fit list; "small" = mprg_kmeans_fit_small (128-thread workgroups, trimmed LDS) likewise."""
+    a class take mprg_kmeans_fit with a fit list; "small" = mprg_kmeans_fit_small (128-thread workgroups, trimmed LDS) likewise;
+    "lds" = mprg_kmeans_fit_lds (round 6: the restarts' state in LDS, dynamic LDS by class) likewise."""
     groups = {}
     for idx, f in enumerate(fits):
         groups.setdefault(f["k"], []).append(idx)
@@ -66,15 +67,17 @@ def run_kmeans_fits(be, fits, n_init=10, path="global", n_slots=3):
         elif path == "one-launch":
             be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), None, P, n_init, be.ptr(d_u), be.ptr(d_x), be.ptr(d_ws), 0, 0, 0, 0,
                     be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
-        elif path in ("wave", "small"):
+        elif path in ("wave", "small", "lds"):
             classify = ((lambda D, V: be.lib.mprg_kmeans_wave_class(D, V, k)) if path == "wave" else
+                        (lambda D, V: be.lib.mprg_kmeans_lds_class(D, V, k, n_init)) if path == "lds" else
                         (lambda D, V: be.lib.mprg_kmeans_small_class(D, V, k, n_init)))
+            entry_of = {"wave": "mprg_kmeans_fit_wave", "small": "mprg_kmeans_fit_small", "lds": "mprg_kmeans_fit_lds"}[path]
             cls = np.asarray([classify(int(ptab[i, 1]), int(ptab[i, 7])) for i in range(P)])
             for c in sorted(set(cls.tolist())):
                 lst = np.nonzero(cls == c)[0].astype(np.int32)
                 d_l = be.upload(lst)
                 if c >= 0:
-                    be.call("mprg_kmeans_fit_wave" if path == "wave" else "mprg_kmeans_fit_small", be.ptr(d_p), be.ptr(d_ki), be.ptr(d_l), len(lst), c, n_init, be.ptr(d_u), be.ptr(d_x),
+                    be.call(entry_of, be.ptr(d_p), be.ptr(d_ki), be.ptr(d_l), len(lst), c, n_init, be.ptr(d_u), be.ptr(d_x),
                             be.ptr(d_ws), be.ptr(d_lab), be.ptr(d_info1), be.ptr(d_st1), be.stream)
                 else:
                     be.call("mprg_kmeans_fit", be.ptr(d_p), be.ptr(d_ki), be.ptr(d_l), len(lst), n_init, be.ptr(d_u), be.ptr(d_x),

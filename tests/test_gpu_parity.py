@@ -64,7 +64,7 @@ def test_kmeans_known_answers_persistent_workgroups(hip, golden_kmeans):
     fits = golden_kmeans["fits"]
     # one-launch: no scratch slots, a workgroup per fit; wave: a wavefront per fit; split / wide: a workgroup (64 / 1 024 threads) per
     # restart + a selection launch
-    for path, slots in (("one-launch", 0), ("wave", 0), ("small", 0), ("split", 0), ("wide", 0), ("wide-bytes", 0), ("wide-stats", 0), ("fit", 5), ("fit", 4096)):
+    for path, slots in (("one-launch", 0), ("wave", 0), ("small", 0), ("lds", 0), ("split", 0), ("wide", 0), ("wide-bytes", 0), ("wide-stats", 0), ("fit", 5), ("fit", 4096)):
         got = run_kmeans_fits(hip, fits, path=path, n_slots=slots)
         for g, f in zip(got, fits):
             assert g["labels"] == f["labels"]

@@ -37,6 +37,7 @@ def test_relocation_matches_oracle():
 def test_relocation_matches_oracle_persistent_workgroups():
     fits = degenerate_fits(7, 60)
     check(EmuBackend(), fits, path="wave")                        # a wavefront per fit, restart state in LDS
+    check(EmuBackend(), fits, path="lds")                         # a workgroup per fit, the state of all restarts in LDS (round 6)
     check(EmuBackend(), fits, path="fit", n_slots=2)              # many fits per workgroup, one scratch slot each
     check(EmuBackend(), fits, path="split")                       # a workgroup per restart, then the selection
     check(EmuBackend(), fits[:12], path="wide")                   # the same with 1 024 threads per restart (big fits)
@@ -58,7 +59,7 @@ def test_fits_with_many_samples():
         lab, dbg = orc.kmeans_fit_predict(M, k, want_debug=True)
         fits.append(dict(shape=[D, V], counts_i16_hex=M.astype("<i2").tobytes().hex(), k=k, labels=lab.tolist(),
                          inertia=float(dbg["inertia"]).hex(), n_iter=dbg["n_iter"]))
-    for path, slots in (("global", 0), ("one-launch", 0), ("wave", 0), ("small", 0), ("fit", 1), ("fit", 64)):
+    for path, slots in (("global", 0), ("one-launch", 0), ("wave", 0), ("small", 0), ("lds", 0), ("fit", 1), ("fit", 64)):
         got = run_kmeans_fits(EmuBackend(), fits, path=path, n_slots=slots)
         for g, f in zip(got, fits):
             assert not g["status"] & 2
@@ -85,6 +86,7 @@ def test_relocation_with_wide_matrices():
     check(EmuBackend(), fits, path="one-launch")
     check(EmuBackend(), fits, path="wave")
     check(EmuBackend(), fits, path="small")
+    check(EmuBackend(), fits, path="lds")
     check(EmuBackend(), fits, path="fit", n_slots=2)
 
 
@@ -99,7 +101,7 @@ def test_fits_outside_the_lds_count_form():
         lab, dbg = orc.kmeans_fit_predict(M, k, want_debug=True)
         fits.append(dict(shape=[D, V], counts_i16_hex=M.astype("<i2").tobytes().hex(), k=k, labels=lab.tolist(),
                          inertia=float(dbg["inertia"]).hex(), n_iter=dbg["n_iter"]))
-    for path, slots in (("global", 0), ("global-nocounts", 0), ("one-launch", 0), ("wave", 0), ("small", 0), ("fit", 2)):
+    for path, slots in (("global", 0), ("global-nocounts", 0), ("one-launch", 0), ("wave", 0), ("small", 0), ("lds", 0), ("fit", 2)):
         got = run_kmeans_fits(EmuBackend(), fits, path=path, n_slots=slots)
         for g, f in zip(got, fits):
             assert not g["status"] & 2
