@@ -454,7 +454,10 @@ def main():
 
     import torch
     import torch.distributed as dist
-    if world > 1:
+    # (MPRG_DIST_FORCE=1 under a launcher: the process group — RCCL by default — also for one rank, so that a one-GPU box exercises
+    #  the barrier and the reductions of the multi-GPU line)
+    grouped = world > 1 or (os.environ.get("MPRG_DIST_FORCE", "0") != "0" and "MASTER_ADDR" in os.environ)
+    if grouped:
         torch.cuda.set_device(local_rank)
         if dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -463,7 +466,7 @@ def main():
     device = torch.device("cuda", local_rank)
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(device)     # the workers synchronise their own streams before they answer "done"
 
@@ -479,12 +482,12 @@ def main():
     counters = {k_: sum(c_[k_] for _, c_, _ in reports) for k_ in reports[0][1]}
     counters["levels"] = max(c_["levels"] for _, c_, _ in reports)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=device if (dist_backend == "nccl" and world > 1) else "cpu")
-    if world > 1:
+    t = torch.tensor([dt], dtype=torch.float64, device=device if (dist_backend == "nccl" and grouped) else "cpu")
+    if grouped:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
-    n_local = torch.tensor([len(seeds)], dtype=torch.float64, device=device if (dist_backend == "nccl" and world > 1) else "cpu")
-    if world > 1:
+    n_local = torch.tensor([len(seeds)], dtype=torch.float64, device=device if (dist_backend == "nccl" and grouped) else "cpu")
+    if grouped:
         dist.all_reduce(n_local, op=dist.ReduceOp.SUM)
     msas_per_step = int(n_local.item())          # strong: --batch; weak: --batch x ranks
     total_msas = msas_per_step * args.steps
@@ -509,9 +512,9 @@ def main():
                      "depends on the CPU it runs on (exact k-means++ / centre ties decided by the last bits of BLAS sums) — parity is to the pinned run")
         except Exception:
             pass
-    if world > 1:
+    if grouped:
         flag = torch.tensor([0 if verified is None else verified["mismatches"]], dtype=torch.float64,
-                            device=device if (dist_backend == "nccl" and world > 1) else "cpu")
+                            device=device if (dist_backend == "nccl" and grouped) else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.SUM)
         if verified is not None:
             verified["mismatches_all_ranks"] = int(flag.item())
@@ -680,8 +683,8 @@ def main():
 
     # whole-job counters (strong scaling: a rank's workers only saw its shard)
     keys = ("launches", "fits", "cells_all", "cells_clustered", "kmeans_bytes", "syncs", "plan_misses", "plan_resumes")
-    cvec = torch.tensor([float(counters.get(k_, 0)) for k_ in keys], dtype=torch.float64, device=device if (dist_backend == "nccl" and world > 1) else "cpu")
-    if world > 1:
+    cvec = torch.tensor([float(counters.get(k_, 0)) for k_ in keys], dtype=torch.float64, device=device if (dist_backend == "nccl" and grouped) else "cpu")
+    if grouped:
         dist.all_reduce(cvec, op=dist.ReduceOp.SUM)
     for k_, v_ in zip(keys, cvec.tolist()):
         counters[k_] = v_
@@ -736,6 +739,7 @@ def main():
                                    "SURVEY.md §8d generator, seeds 0..batch-1), -N 5 -L 7; one step = every alignment of the job, "
                                    "resident, sharded over the ranks by size (--weak: all of them on every rank)",
                        "alignments_per_step": msas_per_step, "alignments_rank0": len(seeds), "parallelism": f"shard{world}",
+                       "process_group": (f"{dist.get_backend()} (world {world}" + (", forced: MPRG_DIST_FORCE" if world == 1 else "") + ")") if grouped else None,
                        "host_worker_processes_per_gpu": W, "cpus_rank0": ncpu, "shard_projection": projection, "km_side_streams": os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0", "single_worker": single, "cli": cli, "deep_alignment": deep,
                        "streams_per_worker": args.streams, "event_timing_in_timed_region": bool(args.profile_timed),
                        "step_includes": "recursion forest (kernels + device-side bookkeeping; the host sizes buffers from one header per "
@@ -757,7 +761,7 @@ def main():
         print(json.dumps(out))
     if th is not None:
         th.join(timeout=30)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
     if verified is not None and (verified["mismatches"] or verified.get("mismatches_all_ranks", 0)):
         sys.exit(3)

@@ -252,7 +252,7 @@ int mprg_kmeans_fit_small(const int64_t *prob, const int32_t *kinfo, const int32
  * side, with the state of ALL restarts (lower / upper bounds, the iteration's distances, labels, centre shifts and norms), the fit's
  * counts (bytes) and the k-means++ seeding's inputs (uniforms, row norms, the sample-sample tables where they fit) in LDS for the
  * whole fit — dynamic LDS sized by the fit's class —; only the centres stay in the problem's workspace.  Best restart and predict()
- * in the same workgroup.  mprg_kmeans_lds_class(D, V, k, n_init): 0..3 (13.5 / 20 / 33.5 / 57 KB of dynamic LDS), or -1 if the fit
+ * in the same workgroup.  mprg_kmeans_lds_class(D, V, k, n_init): 0..4 (13.5 / 20 / 33.5 / 57 / 96 KB of dynamic LDS), or -1 if the fit
  * needs another form (more than 64 distinct sequences, more than 10 restarts, a state beyond the largest class).  Arguments and
  * results as mprg_kmeans_fit_small; every fit of a launch must be of class <= lds_class.
  * Replaces, for these fits, scikit-learn's KMeans.fit + predict behind cluster_sequences.py:262-266. */
@@ -316,7 +316,10 @@ int mprg_cluster_further_bounded(const uint8_t *arena, const int64_t *views, con
  * _LOW on the same stream).  The general and the small launches are independent: a host may put them on different streams. */
 enum { MPRG_LOOP_GENERAL = 1, MPRG_LOOP_SMALL_LOW = 2, MPRG_LOOP_SMALL_HIGH = 4, MPRG_LOOP_SKIP_SMALL = 8,
        MPRG_LOOP_LDS = 16 /* round 6: the LDS form of the fit (mprg_kmeans_fit_lds) inside the loop, one launch per LDS class, BEFORE the other
-                             forms of the call; rounds whose fit has no class are left to MPRG_LOOP_GENERAL (without MPRG_LOOP_SKIP_SMALL) */ };
+                             forms of the call; rounds whose fit has no class are left to MPRG_LOOP_GENERAL (without MPRG_LOOP_SKIP_SMALL) */,
+       MPRG_LOOP_SKIP_LDS = 32 /* with MPRG_LOOP_GENERAL: leave the problems whose NEXT round has an LDS class alone — the general form may then
+                                  run beside the MPRG_LOOP_LDS launches (other stream); a last MPRG_LOOP_GENERAL call without it, after both,
+                                  takes the problems that left the classes on the way */ };
 int mprg_cluster_loop(const int64_t *views, const int64_t *prob, int n_probs, int n_init, const double *uniforms_dev,
                       const int32_t *uniform_offsets_host, const double *xcounts, double *ws, const int32_t *d_of_row,
                       const uint8_t *gcodes, int32_t *scratch, int32_t *labels, int32_t *assign, double *km_info, int32_t *km_status,

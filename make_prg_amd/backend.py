@@ -335,7 +335,7 @@ class HipBackend(_Base):
     def _record(self, event, side):
         event.record(self.stream_obj if side is None else self._side[side])
 
-    n_side_streams = 3
+    n_side_streams = 5
 
     def _sides(self, n):
         if not hasattr(self, "_side"):
@@ -701,7 +701,7 @@ class HipRuntimeBackend(_Base):
     def _record(self, event, side):
         event.record(self.stream if side is None else self._side[side])
 
-    n_side_streams = 3
+    n_side_streams = 5
 
     def _sides(self, n):
         self._on_device()

@@ -50,8 +50,17 @@ static const int g_kp_tiled = [] { const char *e = getenv("MPRG_KP_TILED"); retu
 static const int g_kpw_split = [] { const char *e = getenv("MPRG_KPW_SPLIT"); return (e && atoi(e) == 0) ? 0 : 1; }();
 static const int g_kms_threads = env_threads("MPRG_KMS_THREADS", 128, 128);          // the small KMeans form: 64 or 128 threads per fit
 // the LDS form (k_kmeans_fit_lds): threads per fit by LDS class — the classes with fewer workgroups per CU get more threads
-static const int g_kml_threads[4] = {env_threads("MPRG_KML_THREADS0", 128, 256), env_threads("MPRG_KML_THREADS1", 128, 256),
-                                     env_threads("MPRG_KML_THREADS2", 256, 256), env_threads("MPRG_KML_THREADS3", 256, 256)};
+static const int g_kml_flags = [] { const char *e = getenv("MPRG_KML_FLAGS"); return e ? (atoi(e) & 0x7f) : 0; }();          // tuning switches (k_kmeans_lds.inc)
+static const int g_kml_threads[KML_CLASSES] = {env_threads("MPRG_KML_THREADS0", 128, 256), env_threads("MPRG_KML_THREADS1", 128, 256),
+                                               env_threads("MPRG_KML_THREADS2", 256, 256), env_threads("MPRG_KML_THREADS3", 256, 256),
+                                               env_threads("MPRG_KML_THREADS4", 256, 256)};
+// (the classes beyond 64 KB of LDS per workgroup — static + dynamic — need the limit raised once per kernel)
+template <class K> static int kml_raise_lds(K kernel, bool *raised, const char *what) {
+  if (*raised) return 0;
+  if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KML_C4) != hipSuccess) return fail(what);
+  *raised = true;
+  return 0;
+}
 // small views by a wavefront each, several per workgroup (k_partition_wave, ...): MPRG_WAVE_VIEWS=0 keeps a workgroup per view
 // mprg_cluster_further: problems that fit a workgroup's LDS in one workgroup and launch (k_cluster_further_one); MPRG_CF_ONE=0: two launches for all
 static const int g_cf_one = [] { const char *e = getenv("MPRG_CF_ONE"); return (e && atoi(e) == 0) ? 0 : 1; }();
@@ -402,10 +411,12 @@ int mprg_kmeans_fit_lds(const int64_t *prob, const int32_t *kinfo, const int32_t
                         int32_t *km_status, void *stream) {
   if (n_fits <= 0) return 0;
   if (n_init < 1 || n_init > KML_RMAX) return fail("mprg_kmeans_fit_lds: n_init must be 1..10");
-  if (lds_class < 0 || lds_class >= KML_CLASSES) return fail("mprg_kmeans_fit_lds: lds_class must be 0..3 (mprg_kmeans_lds_class)");
+  if (lds_class < 0 || lds_class >= KML_CLASSES) return fail("mprg_kmeans_fit_lds: lds_class must be 0..4 (mprg_kmeans_lds_class)");
   const int bytes = kml_class_bytes(lds_class);
+  static bool raised = false;
+  if (bytes > 56 * 1024 && kml_raise_lds(k_kmeans_fit_lds, &raised, "mprg_kmeans_fit_lds: the device refuses the LDS of the largest class") != 0) return -1;
   LAUNCH_LDS(k_kmeans_fit_lds, n_fits, g_kml_threads[lds_class], bytes, stream, prob, kinfo, fit_list, n_init, uniforms_dev, xcounts, ws, labels,
-             km_info, km_status, bytes);
+             km_info, km_status, bytes | (g_kml_flags << 24));
   return check_launch("k_kmeans_fit_lds");
 }
 
@@ -485,13 +496,17 @@ static int d_cluster_loop(const int64_t *views, const int64_t *prob, int n_probs
   const bool small_ok = n_init <= KMS_RMAX;
   // the LDS form first, a launch per class in ascending order (a problem whose next round needs more LDS stays active for the next
   // launch; what no class holds is left to the general form below)
+  static bool raised_loop = false;
+  if ((forms & MPRG_LOOP_LDS) && n_init <= KML_RMAX &&
+      kml_raise_lds(k_cluster_loop_lds, &raised_loop, "mprg_cluster_loop: the device refuses the LDS of the largest class") != 0) return -1;
   if ((forms & MPRG_LOOP_LDS) && n_init <= KML_RMAX)
     for (int c = 0; c < KML_CLASSES; ++c)
       LAUNCH_LDS(k_cluster_loop_lds, n_probs, g_kml_threads[c], kml_class_bytes(c), stream, prob, n_init, uniforms_dev, uoff, xcounts, ws, views, d_of_row,
-                 gcodes, scratch, labels, assign, km_info, km_status, num_clusters, active, stats, c, kml_class_bytes(c), dc);
+                 gcodes, scratch, labels, assign, km_info, km_status, num_clusters, active, stats, c, kml_class_bytes(c) | (g_kml_flags << 24), dc);
   if (forms & MPRG_LOOP_GENERAL)
     LAUNCH(k_cluster_loop, n_probs, g_km_threads, stream, prob, n_init, uniforms_dev, uoff, xcounts, ws, views, d_of_row, gcodes, scratch, labels,
-           assign, km_info, km_status, num_clusters, active, stats, (forms & MPRG_LOOP_SKIP_SMALL) && small_ok ? 1 : 0, dc);
+           assign, km_info, km_status, num_clusters, active, stats,
+           (((forms & MPRG_LOOP_SKIP_SMALL) && small_ok) ? 1 : 0) | (((forms & MPRG_LOOP_SKIP_LDS) && n_init <= KML_RMAX) ? 2 : 0), dc);
 #define KLS_LAUNCH(KCH, KHI) hipLaunchKernelGGL((k_cluster_loop_small<KCH, KHI>), dim3((unsigned)n_probs), dim3(128), 0, (hipStream_t)stream, prob, \
                                                  n_init, uniforms_dev, uoff, xcounts, ws, views, d_of_row, gcodes, scratch, labels, assign, \
                                                  km_info, km_status, num_clusters, active, stats, dc)
@@ -824,7 +839,8 @@ int mprg_forest_level(const int64_t *F, void *stream) {
         {
           const int forms = (int)F[MPRG_F_LOOP_FORMS];
           void *side = (void *)(uintptr_t)F[MPRG_F_SIDE_STREAM];
-          const bool split = side && (forms & MPRG_LOOP_GENERAL) && (forms & (MPRG_LOOP_SMALL_LOW | MPRG_LOOP_SMALL_HIGH));
+          const bool lds = (forms & MPRG_LOOP_LDS) != 0;
+          const bool split = side && (forms & MPRG_LOOP_GENERAL) && (lds || (forms & (MPRG_LOOP_SMALL_LOW | MPRG_LOOP_SMALL_HIGH)));
           hipEvent_t e_fork = nullptr, e_join = nullptr;
           if (split) {
             if (hipEventCreateWithFlags(&e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e_join, hipEventDisableTiming) != hipSuccess)
@@ -841,12 +857,20 @@ int mprg_forest_level(const int64_t *F, void *stream) {
                                   FP(int32_t, MPRG_F_ACTIVE), b4, which, on, dp);
           };
           if (split) {
-            if (loop(forms & (MPRG_LOOP_GENERAL | MPRG_LOOP_SKIP_SMALL), stream) != 0) return -1;
-            if (loop(forms & (MPRG_LOOP_SMALL_LOW | MPRG_LOOP_SMALL_HIGH), side) != 0) return -1;
+            if (lds) {
+              // the LDS classes on the side stream, beside them the general form for the problems no class holds; after both the general
+              // form once more, for the (rare) problems that left the classes on the way
+              if (loop(MPRG_LOOP_GENERAL | MPRG_LOOP_SKIP_LDS, stream) != 0) return -1;
+              if (loop(MPRG_LOOP_LDS, side) != 0) return -1;
+            } else {
+              if (loop(forms & (MPRG_LOOP_GENERAL | MPRG_LOOP_SKIP_SMALL), stream) != 0) return -1;
+              if (loop(forms & (MPRG_LOOP_SMALL_LOW | MPRG_LOOP_SMALL_HIGH), side) != 0) return -1;
+            }
             if (hipEventRecord(e_join, (hipStream_t)side) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, e_join, 0) != hipSuccess)
               return fail("mprg_forest_level: join of the side stream");
             // (released by the runtime once the recorded work is done)
             if (hipEventDestroy(e_fork) != hipSuccess || hipEventDestroy(e_join) != hipSuccess) return fail("mprg_forest_level: event release");
+            if (lds && loop(MPRG_LOOP_GENERAL, stream) != 0) return -1;
           } else if (loop(forms, stream) != 0) return -1;
         }
         // ---- S7 MultiClusterNodes and their children

@@ -62,7 +62,7 @@ SPECULATIVE = os.environ.get("MPRG_SPECULATIVE", "1") != "0"
 KM_MODE = int(os.environ.get("MPRG_KM_MODE", "6"))
 KM_LDS_ENTRY = "mprg_kmeans_fit_lds" if (KM_MODE & 4) else "mprg_kmeans_fit_wave"
 KM_LISTS = ((KM_LDS_ENTRY, 0), (KM_LDS_ENTRY, 1), (KM_LDS_ENTRY, 2), (KM_LDS_ENTRY, 3),
-            ("mprg_kmeans_fit", None), ("mprg_kmeans_fit_small", 0), ("mprg_kmeans_fit_small", 1))
+            ("mprg_kmeans_fit", None), ((KM_LDS_ENTRY, 4) if (KM_MODE & 4) else ("mprg_kmeans_fit_small", 0)), ("mprg_kmeans_fit_small", 1))
 # a round's launch lists side by side on side streams: measured flat on MI355X (352 vs 354 ms per forest of 30 000 alignments,
 # profiles/r03/kmeans_forms.md), off by default
 KM_SIDE_STREAMS = os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0"
@@ -435,7 +435,7 @@ class ForestEngine(BatchEngine):
         self._uoffs_host = uoffs
         small = bool(KM_MODE & 2)
         self._set(DS=d_ds, UNIFORMS=self._d_uni, LOOP_FORMS=(16 | 1) if (KM_MODE & 4) else ((1 | 8 | 2 | 4) if small else 1))
-        self.F[FI["SIDE_STREAM"]] = be.side_ptr(0) if (small and KM_SIDE_STREAMS and be.n_side_streams >= 1 and be.side_ptr(0) != be.stream) else 0
+        self.F[FI["SIDE_STREAM"]] = be.side_ptr(0) if ((small or (KM_MODE & 4)) and KM_SIDE_STREAMS and be.n_side_streams >= 1 and be.side_ptr(0) != be.stream) else 0
         self.F[FI["UOFF_HOST"]] = uoffs.ctypes.data
         self.F[FI["CAP"] + CAP_BIG] = max(KM_BIG_BYTES - 1, 0)
         st = dict(caps=caps, d_ds=d_ds, n_words=n_words, reps=[], rec=[], done=0, tries=0)
@@ -774,13 +774,19 @@ class ForestEngine(BatchEngine):
                          be.ptr(dd["d_of_row"]), be.ptr(dd["gcodes"]), be.ptr(d_scratch), be.ptr(d_labels), be.ptr(d_assign), be.ptr(d_info),
                          be.ptr(d_st), be.ptr(d_numcl), be.ptr(d_active), be.ptr(self.d_hdr))
             lds = bool(KM_MODE & 4)
-            side = small and not lds and KM_SIDE_STREAMS and be.profile is None and be.n_side_streams >= 1
+            side = (small or lds) and KM_SIDE_STREAMS and be.profile is None and be.n_side_streams >= 1
             if side:
                 be.fork(1)
-            if lds:          # the LDS form first, a launch per class; then the general form for the rounds no class holds
-                be.call("mprg_cluster_loop", *loop_args, 16, be.stream, label=LOOP_SMALL)
+            if lds:          # the LDS form, a launch per class (beside them, given a side stream, the general form for the problems no class
+                #              holds); then the general form for the rounds that left the classes on the way
+                if side:
+                    be.call("mprg_cluster_loop", *loop_args, 1 | 32, be.stream, label=LOOP_GENERAL)
+                be.call("mprg_cluster_loop", *loop_args, 16, be.side_ptr(0) if side else be.stream, side=0 if side else None, label=LOOP_SMALL)
                 ev = self._last_event(LOOP_SMALL)
                 km_events.append(ev and ev + (LOOP_SMALL,))
+                if side:
+                    be.join(1)
+                    side = False
             be.call("mprg_cluster_loop", *loop_args, 1 | (8 if (small and not lds) else 0), be.stream, label=LOOP_GENERAL)
             ev = self._last_event(LOOP_GENERAL)
             km_events.append(ev and ev + (LOOP_GENERAL,))

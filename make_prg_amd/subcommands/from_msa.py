@@ -65,7 +65,9 @@ def get_all_input_files(input_path: str, suffix: str) -> List[Path]:
 def _dist():
     """(rank, world, dist module or None): a torch.distributed job if the launcher set one up."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    # MPRG_DIST_FORCE=1: a process group (and the multi-rank path: segments, index all-gather, placement) also for ONE rank — what a box
+    # with one GPU can show of the multi-GPU job: the library's kernels, RCCL's communicator and one HIP runtime in one process
+    if world == 1 and (os.environ.get("MPRG_DIST_FORCE", "0") == "0" or "MASTER_ADDR" not in os.environ):
         return 0, 1, None
     import torch
     import torch.distributed as dist

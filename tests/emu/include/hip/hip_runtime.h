@@ -74,6 +74,9 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) {
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(*(double *)b - *(double *)a); return hipSuccess; }
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
+// (diagnostic builds, -DKM_PHASE_TIMING: a "device symbol" is the host array itself)
+template <class T> static inline hipError_t hipMemcpyFromSymbol(void *dst, const T &sym, size_t n) { memcpy(dst, &sym, n); return hipSuccess; }
+template <class T> static inline hipError_t hipMemcpyToSymbol(T &sym, const void *src, size_t n) { memcpy(&sym, src, n); return hipSuccess; }
 
 namespace emu {
 enum { RUNNABLE = 0, AT_BARRIER = 1, AT_WAVE = 2, DONE = 3 };

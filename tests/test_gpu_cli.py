@@ -109,6 +109,31 @@ def test_two_ranks_on_the_gpu_write_the_single_rank_files(tmp_path):
     assert (tmp_path / "one" / "pan.prg.fa").read_text().count(">") >= 39
 
 
+def test_one_rank_under_rccl_writes_the_single_process_files(tmp_path):
+    """The multi-rank path of the command line with RCCL under it, as far as ONE GPU allows: `torchrun --nproc-per-node 1` with
+    MPRG_DIST_FORCE=1 makes the `nccl` process group for the one rank — segments, the index all-gather on DEVICE tensors
+    (allgather_bytes), the one-HIP-runtime check with a live communicator, placement — and the four output files equal the plain run's."""
+    d = tmp_path / "msas"
+    d.mkdir()
+    for seed in range(860, 890):
+        (d / f"gene{seed}.fa").write_text(synth_config_fasta("B" if seed % 3 else "C", seed))
+    env = dict(os.environ, PYTHONPATH=ROOT, MPRG_CHUNK="8")
+    env.pop("MPRG_DIST_BACKEND", None)
+    one, two = tmp_path / "one" / "pan", tmp_path / "two" / "pan"
+    args = ["from_msa", "-i", str(d), "-t", "4", "-O", "a"]
+    res = subprocess.run([sys.executable, "-m", "make_prg_amd"] + args + ["-o", str(one)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29549", "-m", "make_prg_amd"] + args + ["-o", str(two)], cwd=ROOT,
+                         env=dict(env, MPRG_DIST_FORCE="1"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "index exchange" in res.stderr or "index exchange" in res.stdout, (res.stderr[-1500:], res.stdout[-500:])   # (run_ranks ran)
+    names = sorted(p.name for p in (tmp_path / "one").iterdir())
+    assert names == ["pan.prg.bin.zip", "pan.prg.fa", "pan.prg.gfa.zip", "pan.update_DS.zip"] == sorted(p.name for p in (tmp_path / "two").iterdir())
+    for n in names:
+        assert (tmp_path / "one" / n).read_bytes() == (tmp_path / "two" / n).read_bytes(), n
+
+
 def test_command_line_on_one_deep_alignment(tmp_path):
     """The command line on the FASTA file of the parity-checked deep alignment (tests/golden/ddeep.json: 2 000 x 4 000, -N 7; the real
     reference's PRG): levels with big clustering problems take the multi-workgroup forms; every output type is written."""
