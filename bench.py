@@ -709,14 +709,14 @@ def main():
         # exactly these kernel sources; otherwise null
         traffic = traffic_note = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r05", "pmc_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r06", "pmc_summary.json")))
             if pm.get("source_digest") == source_digest():
                 # the PMC passes profile a different batch (8192 alignments in one process), so their bytes per launch are
                 # not this pass's: what carries over is HBM bytes / algorithmic bytes of the entry point, measured there
                 ratio = pm["entry_points"][name]["traffic_over_algorithmic"]
                 traffic = round(ratio * top["algorithmic_bytes_per_launch"], 1)
                 traffic_note = (f"{ratio} x algorithmic bytes: (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes of {name} in the PMC "
-                                f"passes of the same sources (profiles/r05/pmc_summary.json, source_digest {pm['source_digest']})")
+                                f"passes of the same sources (profiles/r06/pmc_summary.json, source_digest {pm['source_digest']})")
         except Exception:
             pass
         roof = dict(bound="hbm", kernel=top["kernel"], entry_point=name, achieved=top["achieved_GBps"] or 0.0,

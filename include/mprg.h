@@ -252,7 +252,7 @@ int mprg_kmeans_fit_small(const int64_t *prob, const int32_t *kinfo, const int32
  * side, with the state of ALL restarts (lower / upper bounds, the iteration's distances, labels, centre shifts and norms), the fit's
  * counts (bytes) and the k-means++ seeding's inputs (uniforms, row norms, the sample-sample tables where they fit) in LDS for the
  * whole fit — dynamic LDS sized by the fit's class —; only the centres stay in the problem's workspace.  Best restart and predict()
- * in the same workgroup.  mprg_kmeans_lds_class(D, V, k, n_init): 0..4 (13.5 / 20 / 33.5 / 57 / 96 KB of dynamic LDS), or -1 if the fit
+ * in the same workgroup.  mprg_kmeans_lds_class(D, V, k, n_init): 0..5 (11.75 / 18.5 / 31.75 / 45 / 71.75 / 128 KB of dynamic LDS: 8 / 6 / 4 / 3 / 2 / 1 workgroups per CU), or -1 if the fit
  * needs another form (more than 64 distinct sequences, more than 10 restarts, a state beyond the largest class).  Arguments and
  * results as mprg_kmeans_fit_small; every fit of a launch must be of class <= lds_class.
  * Replaces, for these fits, scikit-learn's KMeans.fit + predict behind cluster_sequences.py:262-266. */
@@ -496,7 +496,9 @@ int mprg_forest_sizes_fill(const int64_t *F, void *stream);
  *     the wave / general / small workgroup form (doubles), 82 unsupported fit,
  *     84 cells visited by the rounds' mprg_cluster_further (double); reset per call: 83 problems still active, 86-89 fits of
  *     round k for mprg_kmeans_fit_wave per LDS class, 90 fits for mprg_kmeans_fit, 91 / 92 for mprg_kmeans_fit_small class 0 / 1
- *     (listed in MPRG_F_FIT_LISTS; which forms are used: MPRG_F_KM_MODE). */
+ *     (listed in MPRG_F_FIT_LISTS; which forms are used: MPRG_F_KM_MODE — bit 0 the wave form, bit 1 the small workgroup form, bit 2
+ *     (round 6, the hosts' default) the LDS form mprg_kmeans_fit_lds: its classes 0-3 take slots 86-89, classes 4 / 5 slots 91 / 92,
+ *     and the algorithmic bytes of its fits are added to word 81). */
 int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream);
 /* S7  after the loop: hdr: 0 new MultiClusterNodes, 1 their rows, 2 their children.  _fill: tables of mprg_split_children;
  *     _split_children (after it): the nodes become cluster nodes, their children are appended at MPRG_F_N_NODES. */

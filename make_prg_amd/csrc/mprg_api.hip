@@ -53,11 +53,11 @@ static const int g_kms_threads = env_threads("MPRG_KMS_THREADS", 128, 128);     
 static const int g_kml_flags = [] { const char *e = getenv("MPRG_KML_FLAGS"); return e ? (atoi(e) & 0x7f) : 0; }();          // tuning switches (k_kmeans_lds.inc)
 static const int g_kml_threads[KML_CLASSES] = {env_threads("MPRG_KML_THREADS0", 128, 256), env_threads("MPRG_KML_THREADS1", 128, 256),
                                                env_threads("MPRG_KML_THREADS2", 256, 256), env_threads("MPRG_KML_THREADS3", 256, 256),
-                                               env_threads("MPRG_KML_THREADS4", 256, 256)};
+                                               env_threads("MPRG_KML_THREADS4", 256, 256), env_threads("MPRG_KML_THREADS5", 256, 256)};
 // (the classes beyond 64 KB of LDS per workgroup — static + dynamic — need the limit raised once per kernel)
 template <class K> static int kml_raise_lds(K kernel, bool *raised, const char *what) {
   if (*raised) return 0;
-  if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KML_C4) != hipSuccess) return fail(what);
+  if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, KML_C5) != hipSuccess) return fail(what);
   *raised = true;
   return 0;
 }
@@ -411,7 +411,7 @@ int mprg_kmeans_fit_lds(const int64_t *prob, const int32_t *kinfo, const int32_t
                         int32_t *km_status, void *stream) {
   if (n_fits <= 0) return 0;
   if (n_init < 1 || n_init > KML_RMAX) return fail("mprg_kmeans_fit_lds: n_init must be 1..10");
-  if (lds_class < 0 || lds_class >= KML_CLASSES) return fail("mprg_kmeans_fit_lds: lds_class must be 0..4 (mprg_kmeans_lds_class)");
+  if (lds_class < 0 || lds_class >= KML_CLASSES) return fail("mprg_kmeans_fit_lds: lds_class must be 0..5 (mprg_kmeans_lds_class)");
   const int bytes = kml_class_bytes(lds_class);
   static bool raised = false;
   if (bytes > 56 * 1024 && kml_raise_lds(k_kmeans_fit_lds, &raised, "mprg_kmeans_fit_lds: the device refuses the LDS of the largest class") != 0) return -1;

@@ -62,7 +62,8 @@ SPECULATIVE = os.environ.get("MPRG_SPECULATIVE", "1") != "0"
 KM_MODE = int(os.environ.get("MPRG_KM_MODE", "6"))
 KM_LDS_ENTRY = "mprg_kmeans_fit_lds" if (KM_MODE & 4) else "mprg_kmeans_fit_wave"
 KM_LISTS = ((KM_LDS_ENTRY, 0), (KM_LDS_ENTRY, 1), (KM_LDS_ENTRY, 2), (KM_LDS_ENTRY, 3),
-            ("mprg_kmeans_fit", None), ((KM_LDS_ENTRY, 4) if (KM_MODE & 4) else ("mprg_kmeans_fit_small", 0)), ("mprg_kmeans_fit_small", 1))
+            ("mprg_kmeans_fit", None), ((KM_LDS_ENTRY, 4) if (KM_MODE & 4) else ("mprg_kmeans_fit_small", 0)),
+            ((KM_LDS_ENTRY, 5) if (KM_MODE & 4) else ("mprg_kmeans_fit_small", 1)))
 # a round's launch lists side by side on side streams: measured flat on MI355X (352 vs 354 ms per forest of 30 000 alignments,
 # profiles/r03/kmeans_forms.md), off by default
 KM_SIDE_STREAMS = os.environ.get("MPRG_KM_SIDE_STREAMS", "0") != "0"
@@ -221,6 +222,8 @@ class ForestEngine(BatchEngine):
             self._pending = self._spec_enqueue(caps)
         else:
             self._forest_exact()
+            self._publish_donor()          # (the forest is complete: the NEXT engine's first batch — a pipeline's second chunk, begun before this
+            #                                 one's forest_finish — is already sized from it instead of taking the per-step host as well)
 
     def forest_finish(self):
         """Second half of run_forest: waits for a forest that was enqueued from capacities and looks at the device state (a total
@@ -231,7 +234,10 @@ class ForestEngine(BatchEngine):
             self._pending = None
         self._nodes_hint, self._pool_hint = self.n_nodes + (self.n_nodes >> 4), self.pool_used + (self.pool_used >> 4)
         self._forest_end(check_failed=not by_device or self._spec_failed)
-        # the next batch built on this backend — the command line's next chunk, a rank's next shard — is sized from this one
+        self._publish_donor()
+
+    def _publish_donor(self):
+        """The next batch built on this backend — the command line's next chunk, a rank's next shard — is sized from this one."""
         if self._whole_roots and len(self.ok) >= DONOR_MIN_ROOTS:
             donor = self.plan_export()
             if donor is not None:

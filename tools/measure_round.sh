@@ -4,7 +4,7 @@
 #   2. rocprofv3 --kernel-trace --stats of bench.py in its in-process mode (--workers 0: nothing forks under the profiler,
 #      one stream: kernel durations are exclusive)
 #   3. + 4. HBM traffic: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM section)
-tag=${1:-r05}
+tag=${1:-r06}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
