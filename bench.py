@@ -394,8 +394,11 @@ def main():
     #   totals, forest.forest_enqueue) with the clustering loop's general and small forms side by side on a side stream:
     #   76.1 k alignments/s against 67.9 k with one engine and 75.2 k with four worker processes;
     #   a big shard by several worker processes with one engine each (30 000: 95.3 k with four; two engines each: 90.5 k).
+    # Round 6 (profiles/r06/NOTES.md: host shapes): with the LDS form of the KMeans fits several worker processes of one engine each build
+    # such a shard fastest too — first pass, 3 750 alignments: 93.2 k alignments/s with four, 92.1 k with three, 88.4 k with one worker
+    # and two engines (round 5's shape: 76.1 k then) — so a small shard keeps the default shape (MPRG_SHARD_WORKERS: for experiments).
     if args.workers == 4 and len(seeds) <= 5000 and W >= 1:          # (an explicit --workers other than the default is respected)
-        W = 1
+        W = min(W, int(os.environ.get("MPRG_SHARD_WORKERS", "4")))
     if args.streams == 0:
         args.streams = 2 if (W == 1 and len(seeds) <= 12000) else 1
     if W == 1:          # (not --workers 0: the rocprofv3 runs want one kernel at a time)

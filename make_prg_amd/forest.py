@@ -914,6 +914,16 @@ class ForestEngine(BatchEngine):
             cf_events.append(self._last_event("mprg_cluster_further"))
         if spec_k:
             self._alive["SPEC_K"] = (d_labels, d_info, d_st, d_ki)          # (until the level ends: the stream still reads them)
+            if be.profile is not None:
+                # (profiled passes only) the algorithmic bytes of EVERYTHING the one launch fitted — the rounds the loop reached are what
+                # `kmeans_bytes` counts (k_kl_advance), the others are work the reference never does: reported beside it, not inside it
+                ki = be.download(d_ki, np.int32, 5 * n_k * P).reshape(n_k * P, 5)
+                info = be.download(d_info, np.float64, 8 * n_k * P).reshape(n_k * P, 8)
+                pt = be.download(d_ptab, np.int64, PF * P).reshape(P, PF)
+                ran = ki[:, 1] > 0
+                dv = (pt[ki[:, 0], 1] * pt[ki[:, 0], 7]).astype(np.float64)
+                self.counters["kmeans_bytes_launched_at_once"] = self.counters.get("kmeans_bytes_launched_at_once", 0.0) + \
+                    float((8.0 * dv[ran] * (info[ran, 4] + N_INIT)).sum())
 
     def _last_event(self, name):
         prof = self.be.profile

@@ -65,6 +65,10 @@ for p in range(passes):
                                     achieved_GBps=round(v["bytes"] / max(v["ms"], 1e-9) * 1e-6, 3) if v["bytes"] else None)
                                for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])]
         rec["speculative_levels"] = int(eng.counters.get("speculative_levels", 0))
+        # the wide fits' algorithmic bytes twice: of the fits the reference's loop reaches (what `entry_points` credits) and of everything
+        # the all-rounds-at-once launches fitted (work the reference never does, done on CUs that had none)
+        rec["kmeans_bytes_reference_fits"] = float(eng.counters.get("kmeans_bytes", 0.0))
+        rec["kmeans_bytes_launched_at_once"] = float(eng.counters.get("kmeans_bytes_launched_at_once", 0.0))
         be.profile = None
     out["passes"].append(rec)
     print(json.dumps({k: v for k, v in rec.items() if k != "entry_points"}), flush=True)
