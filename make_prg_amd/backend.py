@@ -446,37 +446,15 @@ class HipRuntimeBackend(_Base):
             self._pinned, self._parity, self._retired, self._turns = {}, {}, [], {}
             self._copy_stream = self._ptr(self.lib.mprg_rt_stream_create(), "stream")
 
-    def prewarm_host(self, arenas, rings, threads: int = 4):
-        """Page-locks the upload arenas {key: bytes} and the download rings {group: bytes} (async_depth blocks each) NOW, several at a
-        time on `threads` threads: page-locking is kernel work of ~0.2 s per GB and otherwise falls, block by block, on the first
-        chunks of a pipeline (the first chunk of a 30 000-file run waited 0.26 s for it).  Sizes are estimates: a block that turns
-        out too small is replaced as before."""
-        from concurrent.futures import ThreadPoolExecutor
-        self._on_device()
-        self._init_rings()
-        if not hasattr(self, "_pinned_up"):
-            self._pinned_up = {}
-        depth = getattr(self, "async_depth", 2)
-        want = [("up", k, int(n)) for k, n in arenas.items() if k not in self._pinned_up] + \
-               [("ring", (g, q), int(n)) for g, n in rings.items() for q in range(depth) if (g, q) not in self._pinned]
-        if not want:
-            return
-
-        def alloc(item):
-            self._on_device()          # (HIP's current device is per thread)
-            n = max(item[2] + (item[2] >> 3), 1 << 20)
-            return item, _RtHostBuffer(self._ptr(self.lib.mprg_rt_host_malloc(n), f"page-locked allocation of {n} bytes"), n)
-
-        with ThreadPoolExecutor(max(1, min(threads, len(want)))) as pool:
-            for (kind, key, _), hb in pool.map(alloc, want):
-                self._host.append(hb)
-                (self._pinned_up if kind == "up" else self._pinned)[key] = hb
-
     def clone(self):
         """A second backend on the same device: a compute stream, a copy stream, device free lists and a header block of its OWN —
         and THIS backend's page-locked host memory (the upload arenas by key, the download rings and their turn counters): two
         engines that take a pipeline's chunks in turn (pipeline.py) then cycle through one set of pinned buffers in chunk order,
-        as one engine would, instead of page-locking a second set (0.2 s per GB)."""
+        as one engine would, instead of page-locking a second set (0.2 s per GB).
+        INVARIANT the caller keeps: a shared block is handed to one backend at a time.  `_host_release` (a block that regrows, a retired
+        ring block) waits for the CALLING backend's streams only before it frees page-locked memory — not for the sibling's upload or
+        download that may still use it.  pipeline.py guarantees it with its `slot_free` semaphore (chunk i - 3 is fully written before
+        its buffers are taken again); any other user of clone() must serialise the two backends' use of a block the same way."""
         other = HipRuntimeBackend(self.device)
         self._on_device()
         self._init_rings()

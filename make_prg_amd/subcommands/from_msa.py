@@ -427,17 +427,32 @@ def run_ranks(mine: List[Path], options, backend, dist, rank: int, world: int) -
     opts = copy.copy(options)
     opts.output_prefix = segment_prefix(options, rank, mine)
     t0 = time.perf_counter()
+
+    def agree(ok: bool) -> bool:
+        """AND over the ranks (a MIN all-reduce): a rank that failed on its own tells the others before the next collective."""
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
     try:
-        idx = run_pipeline(mine, opts, backend or (lambda: get_backend("runtime")), segment=True)
-        libs = hip_runtimes_mapped()
-        if len(libs) > 1:
-            raise RuntimeError("two HIP runtimes are mapped into this rank (" + ", ".join(libs) + "): the kernels' library and "
-                               "torch.distributed must share one — import torch before the backend is made")
+        idx, err = None, None
+        try:
+            idx = run_pipeline(mine, opts, backend or (lambda: get_backend("runtime")), segment=True)
+            libs = hip_runtimes_mapped()
+            if len(libs) > 1:
+                raise RuntimeError("two HIP runtimes are mapped into this rank (" + ", ".join(libs) + "): the kernels' library and "
+                                   "torch.distributed must share one — import torch before the backend is made")
+        except Exception as e:          # noqa: BLE001 — told to the other ranks first
+            err = e
+        if not agree(err is None):
+            raise err if err is not None else RuntimeError(f"rank {rank}: another rank failed while building its shard")
         t1 = time.perf_counter()
         got = allgather_bytes(segments.pack_index(idx), dist, rank, world)
         t2 = time.perf_counter()
         n = segments.merge_segments([segments.unpack_index(b) for b in got], options.output_prefix,
-                                    sort_key=lambda locus: locus + ".prg.fa", rank=rank, world=world, barrier=dist.barrier)
+                                    sort_key=lambda locus: locus + ".prg.fa", rank=rank, world=world, barrier=dist.barrier, agree=agree)
         t3 = time.perf_counter()
         logger.info(f"rank {rank}: segments built and written in {t1 - t0:.2f}s, index exchange {t2 - t1:.2f}s, placed in the run's files in {t3 - t2:.2f}s")
         run_ranks.timings = dict(build_write_s=t1 - t0, exchange_s=t2 - t1, place_s=t3 - t2)

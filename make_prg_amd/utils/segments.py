@@ -93,14 +93,47 @@ def _copy_plan(dst_path: str, seg_paths: List[str], seg: np.ndarray, src_off: np
 
 
 def merge_segments(indexes: List[dict], output_prefix: str, sort_key, keep_segments: bool = False, rank: int = 0, world: int = 1,
-                   barrier=None) -> int:
+                   barrier=None, agree=None) -> int:
     """indexes[r]: rank r's segment_index (pipeline.py).  Writes <prefix>.prg.fa, .prg.bin(.zip), .prg.gfa(.zip), .update_DS.zip in
     the run's locus order (sort_key(locus)) and removes the segments.  Returns the number of loci.
     world > 1: called by EVERY rank with the same indexes; rank 0 creates the files and writes the directories, every rank copies its
-    own segment's ranges (barrier(): the job's barrier, between the three steps).  world == 1: one caller does it all."""
+    own segment's ranges (barrier(): the job's barrier, between the three steps).  world == 1: one caller does it all.
+    agree(ok) (optional, world > 1): the job's AND over the ranks' `ok` (a MIN all-reduce) — asked after the files are created and after
+    the copies, so that a rank that failed on its own (no space, no permission) makes EVERY rank raise instead of leaving the others in the
+    next collective until its timeout; rank 0 then removes the half-filled outputs."""
     solo = world == 1
     only = None if solo else rank
     sync = barrier if (barrier is not None and not solo) else (lambda: None)
+    created: List[str] = []
+
+    def settle(err, what):
+        """Every rank learns whether all of them got through `what`; on a failure anywhere: outputs removed (rank 0), everybody raises."""
+        ok = err is None
+        all_ok = agree(ok) if (agree is not None and not solo) else ok
+        if all_ok:
+            return
+        if rank == 0:
+            for path in created:
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
+        if err is not None:
+            raise err
+        raise RuntimeError(f"another rank failed while {what}: the run's output files were removed")
+
+    def allocate(fd, nbytes):
+        """The file at its final size with its blocks reserved (a full disk shows HERE, on rank 0, not in the middle of the ranks' copies)."""
+        try:
+            if nbytes > 0:
+                os.posix_fallocate(fd, 0, nbytes)
+            else:
+                os.ftruncate(fd, 0)
+        except OSError as e:
+            import errno
+            if e.errno not in (errno.EOPNOTSUPP, errno.EINVAL, errno.ENOSYS):
+                raise
+            os.ftruncate(fd, nbytes)
     # ---- the run's order
     loci, rank_of, pos_in_rank = [], [], []
     for r, idx in enumerate(indexes):
@@ -118,6 +151,7 @@ def merge_segments(indexes: List[dict], output_prefix: str, sort_key, keep_segme
     seg_prefix = [idx["prefix"] for idx in indexes]
     plans = []          # (destination, segment paths, seg, src offsets, lengths, destination offsets)
     writers = []        # rank 0: containers whose central directory is written after the copies
+    to_create = []      # rank 0: (path, final size, the container's entries or None for a plain file)
     # ---- <prefix>.prg.fa
     if have_fa:
         src_off = [np.cumsum([0] + [ln for _, ln in idx["fa"]])[:-1] if idx["fa"] else np.zeros(0, np.int64) for idx in indexes]
@@ -127,8 +161,7 @@ def merge_segments(indexes: List[dict], output_prefix: str, sort_key, keep_segme
         do = np.cumsum(ln) - ln
         dst = output_prefix + ".prg.fa"
         if rank == 0:
-            with open(dst, "wb") as fh:
-                fh.truncate(int(ln.sum()))
+            to_create.append((dst, int(ln.sum()), None))
         plans.append((dst, [p + ".prg.fa" for p in seg_prefix], seg, so, ln, do))
     # ---- the containers: members in the run's order, one new central directory
     for kind in kinds:
@@ -148,23 +181,40 @@ def merge_segments(indexes: List[dict], output_prefix: str, sort_key, keep_segme
         so = np.asarray([m[5] for m in members], np.int64)
         if single:
             if rank == 0:
-                with open(dst, "wb") as fh:
-                    fh.truncate(int(size[0]))
+                to_create.append((dst, int(size[0]), None))
             plans.append((dst, [p + _KIND_FILE[kind] for p in seg_prefix], seg, so + head, size, np.zeros(1, np.int64)))
             continue
         ln = head + size
         do = np.cumsum(ln) - ln
         if rank == 0:
-            w = StoredZipWriter(dst, threads=1)
-            w._open()
-            os.ftruncate(w.fd, int(ln.sum()))
-            w.entries = [(m[2].encode("utf-8"), int(m[3]) & 0xFFFFFFFF, int(m[4]), int(o)) for m, o in zip(members, do.tolist())]
-            w.offset = int(ln.sum())
-            writers.append(w)
+            entries = [(m[2].encode("utf-8"), int(m[3]) & 0xFFFFFFFF, int(m[4]), int(o)) for m, o in zip(members, do.tolist())]
+            to_create.append((dst, int(ln.sum()), entries))
         plans.append((dst, [p + _KIND_FILE[kind] for p in seg_prefix], seg, so, ln, do))
+    err = None
+    try:
+        for dst, nbytes, entries in to_create:          # (rank 0 only)
+            created.append(dst)
+            if entries is None:
+                with open(dst, "wb") as fh:
+                    allocate(fh.fileno(), nbytes)
+            else:
+                w = StoredZipWriter(dst, threads=1)
+                w._open()
+                allocate(w.fd, nbytes)
+                w.entries = entries
+                w.offset = nbytes
+                writers.append(w)
+    except Exception as e:          # noqa: BLE001 — told to the other ranks below
+        err = e
+    settle(err, "creating the run's files")
     sync()                # the files exist at their final sizes
-    for dst, paths, seg, so, ln, do in plans:
-        _copy_plan(dst, paths, seg, so, ln, do, only_rank=only)
+    err = None
+    try:
+        for dst, paths, seg, so, ln, do in plans:
+            _copy_plan(dst, paths, seg, so, ln, do, only_rank=only)
+    except Exception as e:          # noqa: BLE001
+        err = e
+    settle(err, "placing the segments' bytes")
     sync()                # every rank's bytes are in place
     for w in writers:
         w.close()

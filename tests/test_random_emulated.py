@@ -173,6 +173,22 @@ def test_clustering_loop_forms_agree(monkeypatch, golden_integration):
     assert pc.check_integration(EmuBackend(), golden_integration) >= 30
 
 
+def test_kmeans_forms_of_earlier_rounds_through_the_forest(monkeypatch, golden_integration):
+    """The default since round 6 is the LDS form of the fits (KM_MODE bit 2: k_kmeans_fit_lds per round, k_cluster_loop_lds fused).  The forms
+    it replaced stay entry points of the ABI: the small / general workgroup forms (KM_MODE = 2) and the general form alone (0), fused and
+    per round — same answers as the oracle / the real reference's goldens."""
+    import make_prg_amd.forest as F
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    for mode, loop in ((2, "fused"), (2, "rounds"), (0, "fused")):
+        monkeypatch.setattr(F, "KM_MODE", mode)
+        monkeypatch.setattr(F, "KM_LDS_ENTRY", "mprg_kmeans_fit_wave")
+        monkeypatch.setattr(F, "KM_LISTS", ((F.KM_LDS_ENTRY, 0), (F.KM_LDS_ENTRY, 1), (F.KM_LDS_ENTRY, 2), (F.KM_LDS_ENTRY, 3), ("mprg_kmeans_fit", None),
+                                            ("mprg_kmeans_fit_small", 0), ("mprg_kmeans_fit_small", 1)))
+        monkeypatch.setattr(F, "KLOOP", loop)
+        pc.check_vs_oracle(EmuBackend(), random_cases(43 + mode, 24), 5, 7)
+        assert pc.check_integration(EmuBackend(), golden_integration) >= 30
+
+
 def test_levels_with_big_problems_take_the_wide_fits(emu, monkeypatch, golden_integration):
     """forest.KM_BIG_BYTES: a level whose largest count matrix reaches it runs the per-round loop with a wide workgroup per restart
     for its general-form fits (mprg_kmeans_fit_wide) — here every level (threshold 1 byte), in an engine whose loop is otherwise the
