@@ -672,7 +672,11 @@ def main():
                 deep_roof = dict(bound="hbm", entry_point=top_e["entry_point"], kernel=KERNEL_OF.get(top_e["entry_point"], "k_kmeans_restart_wide + k_kmeans_select_only_list + k_kmeans_predict_list"),
                                  ms=top_e["ms"], launches=top_e["calls"], algorithmic_bytes=top_e["algorithmic_bytes"], achieved=top_e["achieved_GBps"],
                                  peak=HBM_PEAK_GBS, unit="GB/s", frac=round(top_e["achieved_GBps"] / HBM_PEAK_GBS, 6),
-                                 traffic=None, traffic_note="FETCH_SIZE / WRITE_SIZE passes of the same command: profiles/r05/deep/")
+                                 traffic=None, traffic_note="FETCH_SIZE / WRITE_SIZE passes of the same command: profiles/r05/deep/",
+                                 # the bytes twice: `algorithmic_bytes` (and `frac`) are of the fits the reference's loop reaches; the launches
+                                 # that fit EVERY round of a big level at once also fit rounds it never reaches — work the reference does not do
+                                 kmeans_bytes_reference_fits=ps[0].get("kmeans_bytes_reference_fits"),
+                                 kmeans_bytes_launched_at_once=ps[0].get("kmeans_bytes_launched_at_once"))
             deep = dict(roofline=deep_roof,workload=f"one hierarchical alignment {gold['S']} x {gold['C']} (utils/synthetic.synth_rows_deep seed {gold['seed']}), -N {gold['N']} -L {gold['L']}",
                         seconds=round(min(p_["wall_ms"] for p_ in ps) / 1e3, 3), nodes=ps[-1]["nodes"], levels=ps[-1]["levels"], kmeans_fits=ps[-1]["fits"],
                         prg_identical_to_the_fixture=all(p_["prg_sha256"] == gold["expect"]["prg_sha256"] for p_ in ps),

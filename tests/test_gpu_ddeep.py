@@ -77,7 +77,8 @@ def test_hierarchical_alignment_at_config_d_size_properties():
     prg = eng.assemble_prgs()[0]
     wall = time.perf_counter() - t0
     assert prg is not None and eng.counters.get("speculative_levels", 0) >= 1
-    assert wall < 8.0, f"forest + PRG text took {wall:.1f} s (round 4: 16.6 s, this round: ~3 s)"
+    # (round 4: 16.6 s; rounds 5 / 6: 2.1 s warm, tools/deep_profile.py — this is the process's FIRST forest: + ~0.5 s of first launches)
+    assert wall < 4.0, f"forest + PRG text took {wall:.1f} s: 1.5 x what this build takes"
     tree = parse_prg(prg)                 # (raises unless the markers nest and every site number opens and closes once)
     _prepare(tree)
     distinct = list(dict.fromkeys(r.decode().replace("-", "") for r in rows))

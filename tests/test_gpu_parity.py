@@ -41,6 +41,45 @@ def test_round_lists_on_side_streams(hip, golden_synthetic, monkeypatch):
     assert pc.check_synthetic(hip, golden_synthetic, configs=("B", "C")) >= 40
 
 
+def test_kmeans_forms_of_earlier_rounds(hip, golden_synthetic, monkeypatch):
+    """The default since round 6 is the LDS form of the fits (forest.KM_MODE bit 2).  The small / general workgroup forms it replaced
+    (KM_MODE = 2) stay entry points of the ABI: fused and per round, same trees and PRGs."""
+    import make_prg_amd.forest as F
+    monkeypatch.setattr(F, "KM_MODE", 2)
+    monkeypatch.setattr(F, "KM_LDS_ENTRY", "mprg_kmeans_fit_wave")
+    monkeypatch.setattr(F, "KM_LISTS", ((F.KM_LDS_ENTRY, 0), (F.KM_LDS_ENTRY, 1), (F.KM_LDS_ENTRY, 2), (F.KM_LDS_ENTRY, 3), ("mprg_kmeans_fit", None),
+                                        ("mprg_kmeans_fit_small", 0), ("mprg_kmeans_fit_small", 1)))
+    for loop in ("fused", "rounds"):
+        monkeypatch.setattr(F, "KLOOP", loop)
+        assert pc.check_synthetic(hip, golden_synthetic, configs=("B", "C")) >= 40
+
+
+def test_diagnostic_build_runs_the_fused_loops():
+    """The diagnostic build of the kernels (-DKM_PHASE_TIMING, make_prg_amd/_lib/libmprg_hip_timing.so: clock marks between the phases of
+    a fit) with the FUSED clustering loop on the LDS form, in a process of its own, against the oracle.  (Round 5's diagnostic build
+    faulted in the fused small form, k_cluster_loop_small — profiles/r06/NOTES.md; the LDS loop that replaced it must not.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "make_prg_amd", "_lib", "libmprg_hip_timing.so")
+    if not os.path.exists(lib):
+        pytest.skip("the diagnostic library is not built (tools/phase_timing.py says how)")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tests import parity_common as pc\n"
+            "from tests.random_msas import random_cases\n"
+            "from make_prg_amd.backend import HipRuntimeBackend\n"
+            "from make_prg_amd.utils.synthetic import synth_config_fasta\n"
+            "pc.ENGINE = 'forest'\n"
+            "be = HipRuntimeBackend(0)\n"
+            "assert b'hip gfx950' in be.lib.mprg_version()\n"
+            "eng = pc.check_vs_oracle(be, random_cases(61, 60) + [synth_config_fasta('C', s) for s in range(900, 912)], 5, 7)\n"
+            "assert eng.kloop_fused and eng.counters['fits'] > 300\n" % root)
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, MPRG_HIP_LIB=lib, MPRG_KLOOP="fused"), capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout[-500:], res.stderr[-1500:])
+
+
 def test_compact_columns(hip):
     """A8 on the device (mprg_compact_columns); the tree dumps of the tests above go through it too (node.alignment)."""
     assert pc.check_compact_columns(hip) == 6

@@ -40,6 +40,23 @@ def test_forests_from_a_plan_equal_the_first_and_the_oracle(hip, texts):
         assert dump(eng, len(texts)) == first
 
 
+def test_planned_forests_with_the_general_form_beside_the_lds_classes(hip, texts, monkeypatch):
+    """forest.KM_SIDE_STREAMS in a forest enqueued without waits (what bench.py switches on for a rank with ONE host worker): inside
+    mprg_forest_level the LDS classes of the clustering loop go to the side stream, the general form for the problems no class holds
+    runs beside them and once more after both.  Same trees as the per-step host's first forest."""
+    import make_prg_amd.forest as forest
+    monkeypatch.setattr(forest, "KM_SIDE_STREAMS", True)
+    eng = ForestEngine(hip, 5, 7)
+    eng.load([load_alignment_text(t) for t in texts])
+    eng.run_forest()
+    first = dump(eng, len(texts))
+    for _ in range(2):
+        reset(eng)
+        eng.run_forest()
+        assert eng.counters["syncs"] == 1 and eng.counters.get("plan_misses", 0) == 0
+        assert dump(eng, len(texts)) == first
+
+
 @pytest.mark.parametrize("step,col", [(0, 1), (1, 1), (1, 3), (3, 0), (4, 1), (5, 2)])
 def test_small_capacities_fall_back(hip, texts, step, col):
     eng = ForestEngine(hip, 5, 7)
