@@ -253,7 +253,8 @@ int mprg_kmeans_fit_small(const int64_t *prob, const int32_t *kinfo, const int32
  * counts (bytes) and the k-means++ seeding's inputs (uniforms, row norms, the sample-sample tables where they fit) in LDS for the
  * whole fit — dynamic LDS sized by the fit's class —; only the centres stay in the problem's workspace.  Best restart and predict()
  * in the same workgroup.  mprg_kmeans_lds_class(D, V, k, n_init): 0..5 (11.75 / 18.5 / 31.75 / 45 / 71.75 / 128 KB of dynamic LDS: 8 / 6 / 4 / 3 / 2 / 1 workgroups per CU), or -1 if the fit
- * needs another form (more than 64 distinct sequences, more than 10 restarts, a state beyond the largest class).  Arguments and
+ * needs another form (more than 64 distinct sequences, more than 10 restarts, a state beyond the largest class, a count matrix beyond
+ * MPRG_KMEANS_PREPARE_LDS_MAX — the fit reads the sample-sample tables mprg_kmeans_prepare makes; mprg_kmeans_prepare_big may leave them out).  Arguments and
  * results as mprg_kmeans_fit_small; every fit of a launch must be of class <= lds_class.
  * Replaces, for these fits, scikit-learn's KMeans.fit + predict behind cluster_sequences.py:262-266. */
 int mprg_kmeans_lds_class(int64_t D, int64_t V, int k, int n_init);

@@ -173,6 +173,36 @@ def test_clustering_loop_forms_agree(monkeypatch, golden_integration):
     assert pc.check_integration(EmuBackend(), golden_integration) >= 30
 
 
+def test_problems_prepared_without_tables_stay_with_the_wide_fits(emu, monkeypatch):
+    """A level of big problems prepares the matrices beyond the prepare kernels' LDS (156 KB) by mprg_kmeans_prepare_big — WITHOUT the
+    seeding's sample-sample tables from forest.KM_NO_TABLES_BYTES on.  The LDS form of the fits reads those tables: kml_class leaves
+    such problems to the wide fits even where their restarts' state would fit its largest classes (here: 44 distinct sequences whose
+    ~750 k-mers make a 260 KB matrix; five close clades + noise, so that a seeding from garbage tables changes the answer — a build without
+    the rule fails this test).  Thresholds of 1 byte: every level counts as big, no big problem gets tables."""
+    import numpy as np
+    import make_prg_amd.forest as F
+    monkeypatch.setattr(F, "KM_BIG_BYTES", 1)
+    monkeypatch.setattr(F, "KM_NO_TABLES_BYTES", 1)
+    monkeypatch.setattr(pc, "ENGINE", "forest")
+    texts = []
+    for seed in (92, 97):
+        rng = np.random.default_rng(seed)
+        C = 44
+        base = rng.integers(0, 4, C)
+        clades = []
+        for _ in range(5):
+            y = base.copy(); m = rng.random(C) < 0.3; y[m] = rng.integers(0, 4, int(m.sum())); clades.append(y)
+        rows = []
+        for i in range(44):
+            y = clades[i % 5].copy(); m = rng.random(C) < 0.1; y[m] = rng.integers(0, 4, int(m.sum()))
+            rows.append(np.frombuffer(b"ACGT", np.uint8)[y].tobytes().decode())
+        texts.append("".join(f">w{i}\n{r}\n" for i, r in enumerate(rows)))
+    eng = pc.check_vs_oracle(emu, texts, 2, 7)
+    assert eng._big_seen and int(eng.counters.get("max_problem_bytes", 0)) > 156 * 1024
+    assert emu.lib.mprg_kmeans_lds_class(44, 744, 2, 10) == -1 and emu.lib.mprg_kmeans_lds_class(64, 310, 2, 10) == -1
+    assert emu.lib.mprg_kmeans_lds_class(30, 100, 4, 10) >= 0
+
+
 def test_kmeans_forms_of_earlier_rounds_through_the_forest(monkeypatch, golden_integration):
     """The default since round 6 is the LDS form of the fits (KM_MODE bit 2: k_kmeans_fit_lds per round, k_cluster_loop_lds fused).  The forms
     it replaced stay entry points of the ABI: the small / general workgroup forms (KM_MODE = 2) and the general form alone (0), fused and
