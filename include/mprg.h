@@ -254,7 +254,8 @@ int mprg_kmeans_fit_small(const int64_t *prob, const int32_t *kinfo, const int32
  * whole fit — dynamic LDS sized by the fit's class —; only the centres stay in the problem's workspace.  Best restart and predict()
  * in the same workgroup.  mprg_kmeans_lds_class(D, V, k, n_init): 0..5 (11.75 / 18.5 / 31.75 / 45 / 71.75 / 128 KB of dynamic LDS: 8 / 6 / 4 / 3 / 2 / 1 workgroups per CU), or -1 if the fit
  * needs another form (more than 64 distinct sequences, more than 10 restarts, a state beyond the largest class, a count matrix beyond
- * MPRG_KMEANS_PREPARE_LDS_MAX — the fit reads the sample-sample tables mprg_kmeans_prepare makes; mprg_kmeans_prepare_big may leave them out).  Arguments and
+ * workspace prepared WITHOUT the sample-sample tables: the fit reads them — mprg_kmeans_prepare_big with_tables = 0 leaves them out; the
+ * forest's control steps look that up in the workspace themselves, a caller of this function must know).  Arguments and
  * results as mprg_kmeans_fit_small; every fit of a launch must be of class <= lds_class.
  * Replaces, for these fits, scikit-learn's KMeans.fit + predict behind cluster_sequences.py:262-266. */
 int mprg_kmeans_lds_class(int64_t D, int64_t V, int k, int n_init);
@@ -334,9 +335,10 @@ int mprg_cluster_loop(const int64_t *views, const int64_t *prob, int n_probs, in
  * takes another form, or k >= D), restart slot (k - 2) n_init, uniform_offsets_host[k], (k - 2) labels_per_k}.  The problems'
  * workspaces must hold 9 n_init restart slots (mprg_kmeans_workspace_doubles), labels / km_info / km_status nine slices of
  * labels_per_k / 8 n_probs / n_probs entries: slice k - 2 is what round k's other launches and mprg_cluster_further are given.
- * mode: MPRG_F_KM_MODE (which forms small fits take). */
+ * mode: MPRG_F_KM_MODE (which forms small fits take).  ws (round 6; may be NULL): the problems' workspaces AFTER mprg_kmeans_prepare* —
+ * the LDS form (mode bit 2) takes no fit of a problem that was prepared without the seeding's tables. */
 int mprg_kmeans_speculative_kinfo(const int64_t *prob, int n_probs, int n_init, int mode, const int32_t *uniform_offsets_host,
-                                  long long labels_per_k, int32_t *kinfo_out, void *stream);
+                                  long long labels_per_k, int32_t *kinfo_out, const double *ws, void *stream);
 
 /* A12/A14 — cluster_sequences.py:287-296 + recursion_tree.py:558-572: row lists of the children of MultiClusterNodes.
  * split_info: n_probs x 3 int64 {number of KMeans clusters, offset of the problem's n_rows entries in pool_out,

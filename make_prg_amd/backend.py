@@ -59,7 +59,7 @@ SIGNATURES = {
     "mprg_split_children": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 7),
     "mprg_leaf_jobs": (c_int, [c_void_p, c_int64] + [c_void_p] * 6),
     "mprg_emit_alleles": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
-    "mprg_kmeans_speculative_kinfo": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
+    "mprg_kmeans_speculative_kinfo": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p]),
     "mprg_export_alignments": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, ctypes.c_longlong, c_void_p, c_void_p]),
     "mprg_forest_level": (c_int, [c_void_p, c_void_p]),
     "mprg_forest_state_init": (c_int, [c_void_p, ctypes.c_longlong, ctypes.c_longlong, c_void_p]),

@@ -685,16 +685,16 @@ int mprg_forest_kloop_advance(const int64_t *F, int k, void *stream) {
   if (hipMemsetAsync(FHDR + 86, 0, KL_LISTS * sizeof(int64_t), (hipStream_t)stream) != hipSuccess) return fail("memset");
   LAUNCH(k_kl_advance, KF_GRID(P), 256, stream, P, k, (int)F[MPRG_F_N_INIT], (int)F[MPRG_F_KM_MODE], FP(const int64_t, MPRG_F_PTAB), FP(const int64_t, MPRG_F_SUB),
          FP(int32_t, MPRG_F_NUM_CLUSTERS), FP(int32_t, MPRG_F_ACTIVE), FP(int32_t, MPRG_F_KINFO), FP(const double, MPRG_F_KM_INFO), FP(int32_t, MPRG_F_KM_STATUS),
-         FP(const int32_t, MPRG_F_FURTHER), (int)F[MPRG_F_UOFF + (k <= KM_KMAX ? k : 0)], FP(int32_t, MPRG_F_FIT_LISTS), FHDR);
+         FP(const int32_t, MPRG_F_FURTHER), (int)F[MPRG_F_UOFF + (k <= KM_KMAX ? k : 0)], FP(int32_t, MPRG_F_FIT_LISTS), FHDR, FP(const double, MPRG_F_WS));
   return kf_publish(F, stream, "k_kl_advance");
 }
 int mprg_kmeans_speculative_kinfo(const int64_t *prob, int n_probs, int n_init, int mode, const int32_t *uniform_offsets_host, long long labels_per_k,
-                                  int32_t *kinfo_out, void *stream) {
+                                  int32_t *kinfo_out, const double *ws, void *stream) {
   if (n_probs <= 0) return 0;
   if (!uniform_offsets_host || !kinfo_out) return fail("mprg_kmeans_speculative_kinfo: uniform offsets / output missing");
   KlUoffs u;
   for (int k = 0; k <= KM_KMAX; ++k) u.v[k] = uniform_offsets_host[k];
-  LAUNCH(k_kl_speculate, KF_GRID((long long)n_probs * (KM_KMAX - 1)), 256, stream, (long long)n_probs, n_init, mode, prob, u, labels_per_k, kinfo_out);
+  LAUNCH(k_kl_speculate, KF_GRID((long long)n_probs * (KM_KMAX - 1)), 256, stream, (long long)n_probs, n_init, mode, prob, u, labels_per_k, kinfo_out, ws);
   return check_launch("k_kl_speculate");
 }
 int mprg_forest_splits_count(const int64_t *F, void *stream) { return kf_splits_count(F, KF_HOST, nullptr, stream); }

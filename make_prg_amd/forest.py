@@ -854,7 +854,7 @@ class ForestEngine(BatchEngine):
         round k + 1 then work on slice k - 2 of the labels / km_info / km_status arrays, where the round's fits already are."""
         be = self.be
         d_fl = be.empty(4 * len(KM_LISTS) * P)
-        self._set(FIT_LISTS=d_fl, KM_MODE=KM_MODE)
+        self._set(FIT_LISTS=d_fl, KM_MODE=KM_MODE, WS=d_ws)          # (WS: the control step asks a problem's workspace whether K6 made its tables)
         fit_args = (be.ptr(self._d_uni), be.ptr(d_x), be.ptr(d_ws))
         n_k = MAX_CLUSTERS - 1
         if spec_k:
@@ -863,7 +863,7 @@ class ForestEngine(BatchEngine):
                 uoffs[k_] = o_
             d_labels, d_info, d_st = be.empty(4 * n_k * max(lo, 1)), be.empty(64 * n_k * P), be.zeros(4 * n_k * P)
             d_ki = be.empty(20 * n_k * P)
-            be.call("mprg_kmeans_speculative_kinfo", be.ptr(d_ptab), P, N_INIT, KM_MODE, uoffs.ctypes.data, lo, be.ptr(d_ki), be.stream)
+            be.call("mprg_kmeans_speculative_kinfo", be.ptr(d_ptab), P, N_INIT, KM_MODE, uoffs.ctypes.data, lo, be.ptr(d_ki), be.ptr(d_ws), be.stream)
             be.call("mprg_kmeans_fit_wide", be.ptr(d_ptab), be.ptr(d_ki), 0, n_k * P, N_INIT, *fit_args, be.ptr(d_labels), be.ptr(d_info), be.ptr(d_st),
                     be.ptr(d_xb) if d_xb is not None else 0, be.stream)
             ev = self._last_event("mprg_kmeans_fit_wide")
