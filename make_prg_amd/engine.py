@@ -531,7 +531,7 @@ class BatchEngine:
             probs.append(dict(q=q, ni=ni, nd=nd, S=S, ro=ro, ru=ru, ul=ul, long_reps=long_reps, D=D,
                               occ_off=np.concatenate(([0], np.cumsum(occ))), T=int(occ.sum())))
         if probs:
-            self._run_kmeans_problems(nodes, probs, sub, d_sub, d_rowidx, d_ucodes, d_ulen, tot_rows, tot_cols, dd["d_of_row"])
+            self._run_kmeans_problems(nodes, probs, sub, d_sub, d_rowidx, d_ucodes, d_ulen, tot_rows, tot_cols, dd["d_of_row"], dd["gcodes"])
             for p in probs:
                 new_nodes.extend(self._finish_cluster_node(nodes, p))
         return new_nodes
@@ -548,15 +548,7 @@ class BatchEngine:
             self._uniform_cache["all"] = (self.be.upload(np.concatenate(parts)), offs)
         return self._uniform_cache["all"]
 
-    def _kinfo(self, n_rows: int, k: int, restart_base: int = 0, label_base: int = 0) -> np.ndarray:
-        """Fit descriptors {problem row, k, restart slot base, uniform offset, label base} for rows 0..n_rows-1."""
-        _, offs = self._uniforms_all()
-        ki = np.empty((n_rows, 5), np.int32)
-        ki[:, 0] = np.arange(n_rows)
-        ki[:, 1], ki[:, 2], ki[:, 3], ki[:, 4] = k, restart_base, offs[k], label_base
-        return ki
-
-    def _run_kmeans_problems(self, nodes, probs, sub, d_sub, d_rowidx, d_ucodes, d_ulen, tot_rows, tot_cols, d_dor):
+    def _run_kmeans_problems(self, nodes, probs, sub, d_sub, d_rowidx, d_ucodes, d_ulen, tot_rows, tot_cols, d_dor, d_gcodes):
         be, K = self.be, self.L
         P = len(probs)
         ptab = np.zeros((P, PF), np.int64)
@@ -612,59 +604,36 @@ class BatchEngine:
             return self._cluster_further(d_sub, d_rowidx, sub, ptab[active_idx], k, d_dor, d_labels, None, d_scratch,
                                          d_further)
 
-        active = list(range(P))
-        fur = check(active, 1)
-        active = [i for i, f in zip(active, fur) if f]
-        k = 1
-        while active:
-            k += 1
-            still = []
-            for i in active:
-                p = probs[i]
-                p["num_clusters"] += 1
-                if p["num_clusters"] > MAX_CLUSTERS or p["num_clusters"] == p["D"]:
-                    continue                                 # cluster_sequences.py:258-261
-                still.append(i)
-            active = still
-            if not active:
-                break
-            sub_ptab = ptab[active]
-            d_sp = be.upload(sub_ptab)
-            nA = len(active)
-            d_st = be.zeros(4 * nA)
-            km_work = [0.0]
-            d_ki = be.upload(self._kinfo(nA, k))
-            be.call("mprg_kmeans_restarts", be.ptr(d_sp), be.ptr(d_ki), nA, N_INIT, be.ptr(self._uniforms_all()[0]),
-                    be.ptr(d_x), be.ptr(d_ws), be.ptr(d_st), be.stream)
-            be.call("mprg_kmeans_select", be.ptr(d_sp), be.ptr(d_ki), nA, N_INIT, be.ptr(d_x), be.ptr(d_ws),
-                    be.ptr(d_labels), be.ptr(d_info), be.stream)
-            self.counters["launches"] += 2
-            st = be.download(d_st, np.int32, nA)
-            info = be.download(d_info, np.float64, 8 * nA).reshape(nA, 8)
-            labels_all = be.download(d_labels, np.int32, lo)
-            if (st & 2).any():
+        # cluster_sequences.py:256-274 — `while cluster_further(...): num_clusters += 1; KMeans(num_clusters).fit(X).predict(X)` with its
+        # accept / revert / stop rules — is the LIBRARY's loop (mprg_cluster_loop: the problem's workgroup walks k = 2..10 itself; the
+        # same kernels and the same control as the batch host's forests, forest.py).  Here: the k = 1 check, then one call.
+        fur = check(list(range(P)), 1)
+        if fur.any():
+            d_uni, offs = self._uniforms_all()
+            uoffs = np.zeros(MAX_CLUSTERS + 1, np.int32)
+            for k_, o_ in offs.items():
+                uoffs[k_] = o_
+            d_numcl, d_active = be.upload(np.ones(P, np.int32)), be.upload(fur.astype(np.int32))
+            d_assign, d_stats = be.zeros(4 * lo), be.zeros(8 * 96)
+            args = (be.ptr(d_sub), be.ptr(d_ptab), P, N_INIT, be.ptr(d_uni), uoffs.ctypes.data, be.ptr(d_x), be.ptr(d_ws), be.ptr(d_dor),
+                    be.ptr(d_gcodes), be.ptr(d_scratch), be.ptr(d_labels), be.ptr(d_assign), be.ptr(d_info), be.ptr(d_kmst), be.ptr(d_numcl),
+                    be.ptr(d_active), be.ptr(d_stats))
+            # (the LDS form's classes first, then the general form for the rounds no class holds: include/mprg.h MPRG_LOOP_*)
+            be.call("mprg_cluster_loop", *args, 16, be.stream)
+            be.call("mprg_cluster_loop", *args, 1, be.stream)
+            self.counters["launches"] += 7
+            stats = be.download(d_stats, np.int64, 96)
+            if stats[82]:
                 raise MprgError("KMeans empty-cluster relocation: the selection ran out of frames (more than 5^10 samples in a fit)")
-            nxt = []
-            for a, i in enumerate(active):
-                p = probs[i]
-                self.counters["fits"] += 1
-                kb = 8.0 * p["D"] * p["V"] * (info[a, 4] + N_INIT)
-                self.counters["kmeans_bytes"] += kb
-                km_work[0] += kb
-                p.setdefault("fits", []).append((p["D"], p["V"], k))
-                lab = labels_all[int(ptab[i, 10]):int(ptab[i, 10]) + p["D"]].astype(np.int64)
-                if int(info[a, 3]) < k:                      # cluster_sequences.py:267-273: revert and stop
-                    p["num_clusters"] -= 1
+            numcl = be.download(d_numcl, np.int32, P)
+            assign_all = be.download(d_assign, np.int32, lo)
+            self.counters["fits"] += int(stats[80])
+            self.counters["kmeans_bytes"] += float(stats[85:86].view(np.float64)[0]) + float(stats[93:94].view(np.float64)[0])
+            for i, p in enumerate(probs):
+                if not fur[i]:
                     continue
-                p["assign"] = lab
-                nxt.append(i)
-            if be.profile is not None and be.profile.get("mprg_kmeans_restarts"):
-                a0, a1, _ = be.profile["mprg_kmeans_restarts"][-1]       # algorithmic bytes known only after the fit
-                be.profile["mprg_kmeans_restarts"][-1] = (a0, a1, km_work[0])
-            if not nxt:
-                break
-            fur = check(nxt, k)
-            active = [i for i, f in zip(nxt, fur) if f]
+                p["num_clusters"] = int(numcl[i])
+                p["assign"] = assign_all[int(ptab[i, 10]):int(ptab[i, 10]) + p["D"]].astype(np.int64)
 
     def _finish_cluster_node(self, nodes, p) -> List[int]:
         """cluster_sequences.py:276-296 + recursion_tree.py:457-469, :558-572 on ids."""
@@ -971,7 +940,7 @@ def _bm_cluster(self: BatchEngine, alignment: MSA, kmer_size: int):
     occ = (ul[long_reps] - K + 1).astype(np.int64)
     p = dict(q=0, ni=0, nd=nodes[0], S=S, ro=0, ru=ru, ul=ul, long_reps=long_reps, D=D,
              occ_off=np.concatenate(([0], np.cumsum(occ))), T=int(occ.sum()))
-    eng._run_kmeans_problems(nodes, [p], sub, d_sub, d_rowidx, d_ucodes, d_ulen, S, int(sub[0, 7]), dd["d_of_row"])
+    eng._run_kmeans_problems(nodes, [p], sub, d_sub, d_rowidx, d_ucodes, d_ulen, S, int(sub[0, 7]), dd["d_of_row"], dd["gcodes"])
     k = p["num_clusters"]
     if k == 1 or k == D:
         return single()
