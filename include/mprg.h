@@ -252,7 +252,7 @@ int mprg_kmeans_fit_small(const int64_t *prob, const int32_t *kinfo, const int32
  * side, with the state of ALL restarts (lower / upper bounds, the iteration's distances, labels, centre shifts and norms), the fit's
  * counts (bytes) and the k-means++ seeding's inputs (uniforms, row norms, the sample-sample tables where they fit) in LDS for the
  * whole fit — dynamic LDS sized by the fit's class —; only the centres stay in the problem's workspace.  Best restart and predict()
- * in the same workgroup.  mprg_kmeans_lds_class(D, V, k, n_init): 0..5 (11.75 / 18.5 / 31.75 / 45 / 71.75 / 128 KB of dynamic LDS: 8 / 6 / 4 / 3 / 2 / 1 workgroups per CU), or -1 if the fit
+ * in the same workgroup.  mprg_kmeans_lds_class(D, V, k, n_init): 0..5 (13.5 / 20 / 33.5 / 46.75 / 73.5 / 128 KB of dynamic LDS: 8 / 6 / 4 / 3 / 2 / 1 workgroups per CU), or -1 if the fit
  * needs another form (more than 64 distinct sequences, more than 10 restarts, a state beyond the largest class, a count matrix beyond
  * workspace prepared WITHOUT the sample-sample tables: the fit reads them — mprg_kmeans_prepare_big with_tables = 0 leaves them out; the
  * forest's control steps look that up in the workspace themselves, a caller of this function must know).  Arguments and
