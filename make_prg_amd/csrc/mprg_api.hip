@@ -52,8 +52,8 @@ static const int g_kms_threads = env_threads("MPRG_KMS_THREADS", 128, 128);     
 // the LDS form (k_kmeans_fit_lds): threads per fit by LDS class — the classes with fewer workgroups per CU get more threads
 static const int g_kml_flags = [] { const char *e = getenv("MPRG_KML_FLAGS"); return e ? (atoi(e) & 0x7f) : 0; }();          // tuning switches (k_kmeans_lds.inc)
 static const int g_kml_threads[KML_CLASSES] = {env_threads("MPRG_KML_THREADS0", 128, 256), env_threads("MPRG_KML_THREADS1", 128, 256),
-                                               env_threads("MPRG_KML_THREADS2", 256, 256), env_threads("MPRG_KML_THREADS3", 256, 256),
-                                               env_threads("MPRG_KML_THREADS4", 256, 256), env_threads("MPRG_KML_THREADS5", 256, 256)};
+                                               env_threads("MPRG_KML_THREADS2", 256, 1024), env_threads("MPRG_KML_THREADS3", 256, 1024),
+                                               env_threads("MPRG_KML_THREADS4", 512, 1024), env_threads("MPRG_KML_THREADS5", 1024, 1024)};
 // (the classes beyond 64 KB of LDS per workgroup — static + dynamic — need the limit raised once per kernel)
 template <class K> static int kml_raise_lds(K kernel, bool *raised, const char *what) {
   if (*raised) return 0;
